@@ -1,0 +1,128 @@
+/* include/pt_api.h — C ABI of the MI355X render path (libpt_hip.so).
+ *
+ * The reference has no function-level plugin API: its "render call" is the OpenGL state the
+ * fragment shader consumes plus one glDrawArrays per frame
+ * (/root/reference/src/Main/dispatch.java:693-705).  This ABI accepts exactly that state:
+ * SSBO contents by binding point, texture 0, the two per-frame uniforms, and hands back the
+ * FRAME accumulation image.  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions mirrored from the reference: buffers are caller-owned host memory copied at call
+ * time (glBufferData semantics, e.g. dispatch.java:210); single-threaded per context (one GL
+ * thread, :168); errors are returned as negative codes with a message in pt_last_error()
+ * (the reference throws RuntimeException from its check helpers, :1853-1865).
+ * There is no CPU fallback: every function fails with PT_ERR_NO_DEVICE when no gfx950 device
+ * is usable.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pt_ctx pt_ctx;
+
+enum {
+    PT_OK = 0,
+    PT_ERR_ARG = -1,        /* bad argument / unknown binding */
+    PT_ERR_NO_DEVICE = -2,  /* no usable HIP device */
+    PT_ERR_HIP = -3,        /* a HIP runtime call failed */
+    PT_ERR_SCENE = -4,      /* scene buffers inconsistent (index out of range, BVH deeper than the
+                               reference's int stack[64] (frag.glsl:465), ...) */
+    PT_ERR_UNSUPPORTED = -5 /* feature the reference has but SURVEY.md §2/§8(f) scopes out
+                               (RAYTRACING==0, DEBUG, implicits, material texture maps) */
+};
+
+/* SSBO binding points of frag.glsl:14-77 accepted by pt_set_buffer */
+enum {
+    PT_BIND_ORIGIN = 0,      /* vec3 ORIGIN              dispatch.java:554-560, 628-631 */
+    PT_BIND_ROTATION = 1,    /* vec3 ROTATION            :562-568, 632-635 */
+    PT_BIND_MOUSE = 2,       /* vec3 MOUSE_POS           :570-574, 636-643 */
+    PT_BIND_TRIANGLES = 3,   /* 40 f32 per triangle      :386-424 */
+    PT_BIND_PARAMS = 4,      /* 12 f32 Parameters        :191-211 */
+    PT_BIND_IMPLICITS = 5,   /* ImpData, must be [0]     :429-456 */
+    PT_BIND_ELLIPSOIDS = 7,  /* EllipData                :460-487 */
+    PT_BIND_BVHDATA = 10,    /* 8 f32 per node           :496-504 */
+    PT_BIND_BVHTREE = 11,    /* 3 i32 per node           :505-513 */
+    PT_BIND_LEAFTRIS = 12,   /* i32 triangle ids         :515-523 */
+    PT_BIND_OBJINDICES = 13, /* [count, root ids]        :525-534 */
+    PT_BIND_MATERIALS = 14   /* [48.0, 48 f32/material]  :270-329 */
+};
+
+/* Creates a render context on HIP device `device` for a width x height FRAME image
+ * (glTexStorage2D(GL_RGBA32F, res, res*screenHratio), dispatch.java:186-189).
+ * shard_rank / shard_count select the tile shard this context renders (1 GPU: 0 / 1): the image
+ * is cut into 32x8-pixel tiles dealt round-robin to the ranks. */
+int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count);
+int pt_destroy(pt_ctx* ctx);
+const char* pt_last_error(void);
+
+/* glBufferData / glBufferSubData on the SSBO bound at `binding` (copy at call time). */
+int pt_set_buffer(pt_ctx* ctx, int binding, const void* data, size_t bytes);
+/* Texture upload + bindless handle slot `index` (dispatch.java:334-378): RGBA8, LINEAR, REPEAT.
+ * Only index 0 (the sky, frag.glsl:235-242) is read on the hot path. */
+int pt_set_texture(pt_ctx* ctx, int index, int width, int height, const uint8_t* rgba8);
+
+/* resetTexture(FRAME)                                             dispatch.java:732-735 */
+int pt_reset_frame(pt_ctx* ctx);
+
+/* One frame: glUniform1i(u_frameCount), glUniform1i(u_seed), glDrawArrays(GL_TRIANGLES,0,6)
+ *                                                                  dispatch.java:697-705
+ * Asynchronous on the context's stream. */
+int pt_render(pt_ctx* ctx, int frame_count, int seed);
+/* n_frames consecutive frames (u_frameCount = first_frame .. first_frame+n_frames-1, u_seed =
+ * seeds[i]) rendered as ONE wavefront batch; FRAME is accumulated in frame order, so the result
+ * is bit-identical to n_frames pt_render calls.  Camera/params must not change inside a batch. */
+int pt_render_batch(pt_ctx* ctx, int first_frame, int n_frames, const int32_t* seeds);
+
+/* glFinish() (dispatch.java:598) */
+int pt_synchronize(pt_ctx* ctx);
+
+/* glReadPixels-like read-back of the FRAME image as width*height RGBA32F, row 0 = bottom
+ * (rgb = running sum, a = frame count; frag.glsl:924-933).  Synchronises.  With shard_count > 1
+ * only this shard's pixels are written (others left untouched): the gather across GPUs is the
+ * host layer's single RCCL collective on pt_frame_device(). */
+int pt_read_frame(pt_ctx* ctx, float* rgba_out);
+
+/* Device-resident accumulator of this shard: n_pixels RGBA32F in shard-local pixel order
+ * (shard_count == 1: plain row-major FRAME).  Valid until pt_destroy. */
+int pt_frame_device(pt_ctx* ctx, void** dev_ptr, size_t* n_pixels);
+/* Number of local pixel slots every shard of this image carries (max over ranks; the packed
+ * buffers are padded to it so that an all-gather has equal counts). */
+int pt_shard_slots(int width, int height, int shard_count, size_t* n_slots);
+/* global pixel index (y*width+x) of every local slot of shard `rank`, -1 for padding */
+int pt_shard_map(int width, int height, int shard_rank, int shard_count, int32_t* pixel_index_out, size_t n_slots);
+/* Scatter the all-gathered packed accumulators (shard_count * n_slots RGBA32F, device memory) into
+ * a full width*height RGBA32F image (device memory) on the context's stream. */
+int pt_unshard(pt_ctx* ctx, const void* gathered_dev, void* full_dev);
+
+/* Launch everything on this HIP stream (e.g. torch's current stream) instead of the context's own. */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);
+
+/* Tuning knobs: 0 = path slots in flight (default 1<<20), 1 = count traversal statistics (0/1) */
+int pt_set_option(pt_ctx* ctx, int option, int64_t value);
+
+/* Statistics since the last pt_reset_counters (PT_CNT_* order).  Node/triangle/hit-update counts
+ * are only collected when option 1 is set (they slow the intersect kernel down). */
+enum { PT_CNT_SEGMENTS = 0, PT_CNT_NODES, PT_CNT_TRITESTS, PT_CNT_HITUPD, PT_CNT_SAMPLES, PT_CNT_BOXTESTS,
+       PT_CNT_ITERATIONS, PT_CNT_EXTEND_LAUNCHES, PT_CNT_N };
+int pt_get_counters(pt_ctx* ctx, uint64_t* out, int n);
+int pt_reset_counters(pt_ctx* ctx);
+
+/* Per-kernel device time of the last pt_render/pt_render_batch, measured with HIP events on the
+ * launch stream: kernel 0 = intersect (extend), 1 = shade, 2 = generate, 3 = accumulate.
+ * Synchronises.  launches = number of launches, total_ms = summed duration. */
+int pt_kernel_time(pt_ctx* ctx, int kernel, int64_t* launches, double* total_ms);
+int pt_set_timing(pt_ctx* ctx, int enabled);
+
+/* Debug / parity probes (used by tests): evaluates the device numeric contract.
+ * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; host pointers, n elements. */
+int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, size_t n);
+/* Single rays through the intersect kernel: o,d are n*3 f32 (host); out is n*4 f32 (t,u,v) + prim as int bits */
+int pt_debug_intersect(pt_ctx* ctx, const float* o, const float* d, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,409 @@
+// pt_device.hpp — device-side data layout and the per-lane building blocks of the wavefront
+// path tracer (gfx950).  The kernels that schedule them live in pt_hip.hip.
+//
+// Reference semantics restated here (all citations into /root/reference/src/shaders/frag.glsl):
+//   rayBox :408-419, rayTri :351-372, rayEllipsoid :373-384, rayBVH :452-537, rayScene :548-653,
+//   RNG :686-708, fresnelReflectAmount :726-743, chooseRay :745-809, trace loop body :820-880,
+//   sample set-up in main :894-910, bgCol :235-242, index stack :136-158.
+#pragma once
+#include "pt_math.hpp"
+
+namespace ptd {
+using namespace pm;
+
+// ------------------------------------------------------------------------------------------------
+// Device-private scene layout (built on the host from the reference's SSBO contents; traversal
+// ORDER is untouched, only the bytes move — SURVEY.md Q-12).
+//
+//  inner node  = 4 x float4 (64 B): both children's boxes + both child references, so one record
+//                per node visit replaces BVHtree[3n+1..2] + 2 x BVHdata rows of the reference:
+//                  q0 = lmin.xyz, lmax.x   q1 = lmax.yz, rmin.xy   q2 = rmin.z, rmax.xyz
+//                  q3 = (lref, rref, 0, 0) as int bits
+//                child reference: >= 0 inner-node index (BFS order over all objects, so the top
+//                levels are the first records = the LDS-staged tile); < 0 leaf whose first
+//                triangle record is -(ref+1); REF_EMPTY = leaf without triangles.
+//  triangle    = 3 x float4 (48 B) in LEAF order (leafTriIndices already applied):
+//                  t0 = v1.xyz, e1.x   t1 = e1.yz, e2.xy   t2 = e2.z, id|last<<31, 0, 0
+//                e1 = v2-v1, e2 = v3-v1 are the same binary32 subtractions rayTri performs.
+//  shading rec = 4 x float4 (64 B) indexed by triangle id: n1, n2, vt1, vt2, vt3, material
+//                (the part of the 160-B reference triangle that only the winning hit needs).
+// ------------------------------------------------------------------------------------------------
+constexpr int REF_EMPTY = (int)0x80000000;
+constexpr int PRIM_NONE = -1;
+constexpr int PRIM_ELLIPSOID = 0x40000000;
+
+struct ObjRoot { float bmin[3]; float bmax[3]; int ref; int pad; };           // 32 B
+struct EllipRec {                                                                // frag.glsl:606-631
+    float c[3], st[3], r; int mat; int rotated; float rot[3]; float R[9]; float RB[9]; float pad[2];
+};
+struct MatRec {                                                                  // the mtl fields trace()/chooseRay() read
+    float Kd[3], Ks[3], Ke[3], Tf[3]; float Tr, Ni, Density, Pm, Pr, Pc, Pcr, subsurface; int illum; int pad[3];
+};                                                                               // 24 dwords = 96 B
+
+struct FrameConst {            // uniform per batch; written by k_frame_setup
+    float screenSize, focalLength, resolution, screenHratio, SAMPLE_RES, MAX_BOUNCES, BLUR, FOCAL_DISTANCE, AUTO_FOCUS;
+    float origin[3], rotation[3], mouse[3];
+    float camRot[9];           // rotationMatrix(ROTATION), row-major math matrix
+    float focus;               // internal_focal_distance of frag.glsl:900-906 (auto-focus ray hoisted)
+    float midToScene;
+};
+
+struct DevScene {
+    const float4* nodes;  int nNodes;        // inner nodes
+    const float4* tris;   int nTriRecs;      // leaf-ordered triangle records
+    const float4* shade;  int nTris;         // by triangle id
+    const ObjRoot* roots; int numObj;
+    const EllipRec* ellip; int numEllip;
+    const MatRec* mats;   int numMat;
+    const uchar4* sky;    int skyW, skyH;
+    int ldsNodes, ldsTris;                   // how many leading node / triangle records the intersect kernel stages in LDS
+};
+
+struct Counters { unsigned nodes = 0, tritests = 0, hitupd = 0, boxtests = 0; };
+
+// ------------------------------------------------------------------------------------------------
+// Intersection
+// ------------------------------------------------------------------------------------------------
+PM_DEV float rayBox(vec3 o, vec3 invD, float mnx, float mny, float mnz, float mxx, float mxy, float mxz) {
+    float tminx = (mnx - o.x) * invD.x, tminy = (mny - o.y) * invD.y, tminz = (mnz - o.z) * invD.z;
+    float tmaxx = (mxx - o.x) * invD.x, tmaxy = (mxy - o.y) * invD.y, tmaxz = (mxz - o.z) * invD.z;
+    float t1x = minnum(tminx, tmaxx), t1y = minnum(tminy, tmaxy), t1z = minnum(tminz, tmaxz);
+    float t2x = maxnum(tminx, tmaxx), t2y = maxnum(tminy, tmaxy), t2z = maxnum(tminz, tmaxz);
+    float tNear = maxnum(maxnum(t1x, t1y), t1z);
+    float tFar = minnum(minnum(t2x, t2y), t2z);
+    return (tFar >= tNear && tFar > 0.0f) ? (tNear > 0.0f ? tNear : 0.0f) : 1e30f;
+}
+
+// Moeller-Trumbore exactly as rayTri; returns 1e30 in t on a miss
+PM_DEV void rayTri(vec3 o, vec3 d, vec3 v1, vec3 e1, vec3 e2, float& t, float& u, float& v) {
+    const float EPSILON = 1e-10f;
+    t = 1e30f; u = 0.0f; v = 0.0f;
+    vec3 dCross_e2 = cross(d, e2);
+    float det = dot(e1, dCross_e2);
+    if (__builtin_fabsf(det) < EPSILON) return;
+    float invDet = 1.0f / det;
+    vec3 s = o - v1;
+    float uu = dot(s, dCross_e2) * invDet;
+    if (uu < 0.0f || uu > 1.0f) return;
+    vec3 sCross_e1 = cross(s, e1);
+    float vv = dot(d, sCross_e1) * invDet;
+    if (vv < 0.0f || uu + vv > 1.0f) return;
+    float tt = dot(e2, sCross_e1) * invDet;
+    if (tt > EPSILON) { t = tt; u = uu; v = vv; }
+}
+
+PM_DEV float rayEllipsoid(vec3 o, vec3 d, vec3 c, float r, float f, float g, float h) {
+    vec3 oc = o - c;
+    float a = f * d.x * d.x + g * d.y * d.y + h * d.z * d.z;
+    float b = 2.0f * (f * oc.x * d.x + g * oc.y * d.y + h * oc.z * d.z);
+    float C = f * oc.x * oc.x + g * oc.y * oc.y + h * oc.z * oc.z - r * r;
+    float Disc = b * b - 4.0f * a * C;
+    float sq = __builtin_sqrtf(Disc);
+    float t = (sq - b) / (2.0f * a);
+    float tAlt = (-b - sq) / (2.0f * a);
+    if ((Disc > 0.0f && (tAlt > 0.0f)) || (t > 0.0f)) return (t > tAlt ? tAlt : t);
+    return 1e30f;
+}
+
+PM_DEV vec3 vecmat(vec3 p, const float* M) {   // p * M, M row-major: component j = dot(p, column j)
+    return v3(dot(p, v3(M[0], M[3], M[6])), dot(p, v3(M[1], M[4], M[7])), dot(p, v3(M[2], M[5], M[8])));
+}
+
+// rayScene's closest-hit search (frag.glsl:548-631) for one ray.  `stk`/`stride`: this lane's
+// traversal stack (LDS).  `ldsN`/`ldsT`: LDS copies of the first sc.ldsNodes / sc.ldsTris records.
+// Visit order, pruning tests and tie-breaks are the reference's (push far child first; prune
+// only at push time; strict '<' on hits), so counters equal the oracle's.
+template <bool COUNT>
+PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int stride, const float4* ldsN, const float4* ldsT,
+                           float& outT, float& outU, float& outV, int& outPrim, Counters& cnt) {
+    vec3 o = madd(d, 1e-4f, oIn);                                  // o = o + 1e-4*d  (:549)
+    vec3 invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float closest = 1e30f, hu = 0.0f, hv = 0.0f;
+    int prim = PRIM_NONE;
+    for (int ob = 0; ob < sc.numObj; ob++) {
+        const ObjRoot R = sc.roots[ob];
+        if (COUNT) cnt.boxtests++;
+        if (rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]) > closest) continue;   // :468
+        int sp = 0;
+        stk[0] = R.ref; sp = 1;
+        while (sp > 0) {
+            int ref = stk[(--sp) * stride];
+            if (COUNT) cnt.nodes++;
+            if (ref >= 0) {
+                float4 q0, q1, q2, q3;
+                if (ref < sc.ldsNodes) { q0 = ldsN[4 * ref]; q1 = ldsN[4 * ref + 1]; q2 = ldsN[4 * ref + 2]; q3 = ldsN[4 * ref + 3]; }
+                else { const float4* p = sc.nodes + 4 * (size_t)ref; q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+                if (COUNT) cnt.boxtests += 2;
+                float Ld = rayBox(o, invD, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                float Rd = rayBox(o, invD, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
+                bool pl = Ld < closest, pr = Rd < closest;
+                if (COUNT) { if (pl && lref == REF_EMPTY) cnt.nodes++; if (pr && rref == REF_EMPTY) cnt.nodes++; }
+                pl = pl && lref != REF_EMPTY; pr = pr && rref != REF_EMPTY;
+                if (Ld > Rd) {                                      // :525-531: far child first, near child popped first
+                    if (pl) { stk[sp * stride] = lref; sp++; }
+                    if (pr) { stk[sp * stride] = rref; sp++; }
+                } else {
+                    if (pr) { stk[sp * stride] = rref; sp++; }
+                    if (pl) { stk[sp * stride] = lref; sp++; }
+                }
+            } else {
+                int ti = -(ref + 1);
+                bool last;
+                do {
+                    float4 t0, t1, t2;
+                    if (ti < sc.ldsTris) { t0 = ldsT[3 * ti]; t1 = ldsT[3 * ti + 1]; t2 = ldsT[3 * ti + 2]; }
+                    else { const float4* p = sc.tris + 3 * (size_t)ti; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+                    unsigned idl = __float_as_uint(t2.y);
+                    last = (idl >> 31) != 0;
+                    float t, u, v;
+                    if (COUNT) cnt.tritests++;
+                    rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
+                    if (t > 0.0f && t < closest) {                  // :489
+                        closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
+                        if (COUNT) cnt.hitupd++;
+                    }
+                    ti++;
+                } while (!last);
+            }
+        }
+    }
+    for (int i = 0; i < sc.numEllip; i++) {                         // :606-631
+        const EllipRec& E = sc.ellip[i];
+        vec3 c = v3(E.c[0], E.c[1], E.c[2]);
+        float t;
+        if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), c, E.r, E.st[0], E.st[1], E.st[2]);
+        else t = rayEllipsoid(o, d, c, E.r, E.st[0], E.st[1], E.st[2]);
+        if (t < closest) { closest = t; prim = PRIM_ELLIPSOID | i; }
+    }
+    outT = closest; outU = hu; outV = hv; outPrim = prim;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RNG (PCG hash), frag.glsl:686-708
+// ------------------------------------------------------------------------------------------------
+PM_DEV uint32_t NextRandom(uint32_t& state) {
+    state = state * 747796405u + 2891336453u;
+    uint32_t result = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    result = (result >> 22u) ^ result;
+    return result;
+}
+PM_DEV float random_(uint32_t& state) { return (float)NextRandom(state) / 4294967295.0f; }
+PM_DEV float randValNormalDist(uint32_t& st) {
+    float theta = 2.0f * 3.1415926f * random_(st);
+    float rho = __builtin_sqrtf(-2.0f * log_(random_(st)));
+    return rho * cos_(theta);
+}
+PM_DEV vec3 randLambertianDistVec(uint32_t& st) {
+    float x = randValNormalDist(st), y = randValNormalDist(st), z = randValNormalDist(st);
+    return v3(x, y, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Path state of one lane (registers); stored SoA in groups of float4 (see pt_hip.hip)
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t FL_INOBJ = 1u << 20, FL_APPLYABS = 1u << 21, FL_ALIVE = 1u << 31;
+
+struct Path {
+    vec3 O, D;             // current ray
+    vec3 col, inc;         // throughput, incLight of the current sample
+    vec3 sum;              // sum of samples of the current pixel-frame
+    uint32_t rng, job;
+    int bounce, sample, stackSize;
+    bool inObj, applyAbs, alive;
+    vec3 enter; float dist;   // RAY_ENTER_LOCATION, DISTANCE_TRAVELED
+    float s[10];           // refractionIndiceStack
+};
+
+PM_DEV uint32_t packFlags(const Path& p) {
+    return (uint32_t)p.bounce | ((uint32_t)p.sample << 8) | ((uint32_t)p.stackSize << 16) | (p.inObj ? FL_INOBJ : 0u) |
+           (p.applyAbs ? FL_APPLYABS : 0u) | (p.alive ? FL_ALIVE : 0u);
+}
+PM_DEV void unpackFlags(Path& p, uint32_t f) {
+    p.bounce = f & 0xff; p.sample = (f >> 8) & 0xff; p.stackSize = (f >> 16) & 0xf;
+    p.inObj = f & FL_INOBJ; p.applyAbs = f & FL_APPLYABS; p.alive = f & FL_ALIVE;
+}
+
+// index stack, frag.glsl:139-158, as a shift array with static indices (stale slots stay readable)
+PM_DEV void addToIndiceStack(Path& p, float e) {
+    if (p.stackSize < 10) {
+#pragma unroll
+        for (int i = 9; i > 0; i--) if (i <= p.stackSize) p.s[i] = p.s[i - 1];
+        p.s[0] = e;
+        p.stackSize++;
+    }
+}
+PM_DEV void removeFirstOfIndiceStack(Path& p) {
+    if (p.stackSize > 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) if (i < p.stackSize - 1) p.s[i] = p.s[i + 1];
+        p.stackSize--;
+    }
+}
+
+// texture(textures[0], uv): GL 4.6 §8.14 LINEAR/REPEAT on RGBA8 (dispatch.java:349-354)
+PM_DEV int imod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
+PM_DEV vec3 sampleSky(const DevScene& sc, float u, float v) {
+    int w = sc.skyW, h = sc.skyH;
+    float fu = u * (float)w - 0.5f, fv = v * (float)h - 0.5f;
+    float flu = (__builtin_fabsf(fu) < 1.0e9f) ? __builtin_floorf(fu) : 0.0f;
+    float flv = (__builtin_fabsf(fv) < 1.0e9f) ? __builtin_floorf(fv) : 0.0f;
+    float a = fu - flu, b = fv - flv;
+    int i0 = imod((int)flu, w), j0 = imod((int)flv, h);
+    int i1 = imod(i0 + 1, w), j1 = imod(j0 + 1, h);
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    uchar4 p00 = sc.sky[j0 * w + i0], p10 = sc.sky[j0 * w + i1], p01 = sc.sky[j1 * w + i0], p11 = sc.sky[j1 * w + i1];
+    vec3 r;
+    r.x = w00 * ((float)p00.x / 255.0f) + w10 * ((float)p10.x / 255.0f) + w01 * ((float)p01.x / 255.0f) + w11 * ((float)p11.x / 255.0f);
+    r.y = w00 * ((float)p00.y / 255.0f) + w10 * ((float)p10.y / 255.0f) + w01 * ((float)p01.y / 255.0f) + w11 * ((float)p11.y / 255.0f);
+    r.z = w00 * ((float)p00.z / 255.0f) + w10 * ((float)p10.z / 255.0f) + w01 * ((float)p01.z / 255.0f) + w11 * ((float)p11.z / 255.0f);
+    return r;
+}
+PM_DEV vec3 bgCol(const DevScene& sc, vec3 In) {
+    float u = 0.5f + atan2_(In.z, In.x) / (2.0f * 3.14159f);
+    float v = 0.5f - asin_(In.y) / 3.14159f;
+    return sampleSky(sc, u, v);
+}
+
+PM_DEV float fresnelReflectAmount(float n1, float n2, vec3 normal, vec3 incidence) {
+    float r0 = (n1 - n2) / (n1 + n2);
+    r0 *= r0;
+    float cosX = -dot(normal, incidence);
+    if (n1 > n2) {
+        float n = n1 / n2;
+        float sinT2 = n * n * (1.0f - cosX * cosX);
+        if (sinT2 > 1.0f) return 1.0f;
+        cosX = __builtin_sqrtf(1.0f - sinT2);
+    }
+    float x = 1.0f - cosX;
+    return r0 + (1.0f - r0) * x * x * x * x * x;
+}
+
+// chooseRay, frag.glsl:745-809
+PM_DEV vec3 chooseRay(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint32_t& rng, int& winType) {
+    float reflectionWeight = 1.0f - m.Pr;
+    float clearcoatWeight = m.Pc;
+    float transmissionWeight = (m.Tr > 0.0f ? m.Tr : (m.Tf[0] > 0.0f ? (m.Tf[0] + m.Tf[1] + m.Tf[2]) / 3.0f : 0.0f));
+    float subsurfaceWeight = m.subsurface;
+    float eta = n1 / n2;
+    float fresnel = 0.0f;
+    if (m.illum == 5 || m.illum == 7 || transmissionWeight > 0.0f) {
+        fresnel = fresnelReflectAmount(n1, n2, N, D);
+        reflectionWeight += fresnel * m.Pr;
+        transmissionWeight *= (1.0f - fresnel);
+    }
+    float diffuseWeight = (1.0f - m.Pm) * (1.0f - transmissionWeight) * (1.0f - fresnel);
+    float totalWeight = diffuseWeight + reflectionWeight + clearcoatWeight + transmissionWeight;
+    reflectionWeight /= totalWeight; clearcoatWeight /= totalWeight; transmissionWeight /= totalWeight;
+    float roll = random_(rng);
+    vec3 outDir;
+    if (roll < reflectionWeight) {
+        winType = 1;
+        outDir = mix(reflect(D, N), normalize(randLambertianDistVec(rng) + N), 0.0f);     // Q-8
+    } else if (roll < reflectionWeight + clearcoatWeight) {
+        winType = 2;
+        outDir = mix(reflect(D, N), normalize(randLambertianDistVec(rng) + N), m.Pcr);
+    } else if (roll < reflectionWeight + clearcoatWeight + transmissionWeight) {
+        winType = 3;
+        outDir = refract(D, N, eta);
+    } else {
+        winType = 0;
+        if (subsurfaceWeight > 0.0f) { if (random_(rng) < subsurfaceWeight) winType = 4; }
+        outDir = normalize(randLambertianDistVec(rng) + N);
+    }
+    return outDir;
+}
+
+// Sample set-up of main(), frag.glsl:885-910, for global pixel (px,py): new camera ray + trace() prologue (:811-818).
+PM_DEV void startSample(const FrameConst& fc, int W, int H, int px, int py, Path& p) {
+    float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
+    vec3 q = v3(((tcx * 2.0f - 1.0f) * -1.0f) * fc.screenSize, ((tcy * 2.0f - 1.0f) * fc.screenHratio) * fc.screenSize, fc.focalLength);
+    vec3 direction = vecmat(q, fc.camRot);
+    vec3 ORIGIN = v3(fc.origin[0], fc.origin[1], fc.origin[2]);
+    vec3 origin_jittered = ORIGIN + vecmat(randLambertianDistVec(p.rng) * fc.BLUR, fc.camRot);
+    vec3 focal_point = ORIGIN + direction * fc.focus;
+    p.D = normalize(focal_point - origin_jittered);
+    p.O = origin_jittered;
+    p.col = v3(1.0f); p.inc = v3(0.0f);
+    p.stackSize = 0;                       // clearIndiceStack
+    addToIndiceStack(p, 1.0029f);
+    p.inObj = false;
+    p.bounce = 0;
+}
+
+// rngState = index + u_seed (:886,:896) for global pixel (px,py); false when the fragment returns early (:887)
+PM_DEV bool pixelIndex(const FrameConst& fc, int W, int H, int px, int py, uint32_t& index) {
+    float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
+    float resY = fc.resolution * fc.screenHratio;
+    int pcx = (int)(tcx * fc.resolution), pcy = (int)(tcy * resY);
+    index = (uint32_t)pcy * (uint32_t)fc.resolution + (uint32_t)pcx;
+    return !(pcx >= (int)fc.resolution || pcy >= (int)resY);
+}
+PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :888, FRAME is left untouched there
+    return __builtin_fabsf((float)px - fc.mouse[0]) < fc.resolution * 0.005f && __builtin_fabsf((float)py - fc.mouse[1]) < fc.resolution * 0.005f;
+}
+
+// One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
+// Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
+template <bool TRANS>
+PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim) {
+    p.bounce++;                                               // :821
+    if (prim == PRIM_NONE || !(ht < 1e25f)) {                 // hit.id > -1 (:823) / closest_t < 1e25 (:634)
+        p.inc = p.inc + bgCol(sc, p.D) * p.col;              // :877
+        return true;
+    }
+    vec3 D = p.D;
+    vec3 o = madd(D, 1e-4f, p.O);
+    vec3 loc = madd(D, ht, o);                                // result.loc = o + closest_t*d (:635)
+    vec3 N; int mat;
+    if (prim & PRIM_ELLIPSOID) {
+        const EllipRec& E = sc.ellip[prim & 0xffffff];
+        vec3 c = v3(E.c[0], E.c[1], E.c[2]);
+        if (E.rotated) N = normalize(vecmat(loc - c, E.RB)); else N = normalize(loc - c);     // :622-626
+        mat = E.mat;
+    } else {
+        const float4* S = sc.shade + 4 * (size_t)prim;
+        float4 s0 = S[0], s1 = S[1], s2 = S[2];
+        vec3 n1 = v3(s0.x, s0.y, s0.z), n2 = v3(s0.w, s1.x, s1.y);
+        if (n1.x != 0.0f && n1.y != 0.0f && n1.z != 0.0f) N = normalize(n2 * hu + n2 * hv + n1 * (1.0f - hu - hv));   // :501-504 (Q-3)
+        else N = n2;                                                                                             // :506 (Q-4)
+        mat = __float_as_int(s2.w);
+    }
+    const MatRec m = sc.mats[mat];
+    p.O = loc;                                                // :824
+    float ND = dot(N, D);
+    N = N * (ND > 0.0f ? -1.0f : 1.0f);                       // :830
+    float n1 = 1.0f, n2 = 1.0f;
+    if (TRANS) {
+        if (ND < 0.0f) { addToIndiceStack(p, m.Ni); n1 = p.s[1]; n2 = p.s[0]; }           // :833-836
+        else { n1 = p.s[0]; n2 = p.s[1]; removeFirstOfIndiceStack(p); }                    // :838-840
+    }
+    int w = 0;
+    vec3 newD = chooseRay(m, n1, n2, N, D, p.rng, w);         // :843
+    p.D = newD;
+    if (TRANS && w == 3) {                                    // :847-863
+        if (ND < 0.0f) {
+            if (p.inObj) { p.dist = distance(p.enter, p.O); p.applyAbs = true; }
+            p.inObj = true;
+            p.enter = p.O;
+        } else {
+            p.inObj = false;
+            p.dist = distance(p.enter, p.O);
+            p.applyAbs = true;
+        }
+    }
+    vec3 Ke = v3(m.Ke[0], m.Ke[1], m.Ke[2]);
+    p.inc = p.inc + Ke * p.col;                               // :865
+    if (length(p.col) < 0.1f) return true;                    // :866
+    if (TRANS && p.applyAbs) {
+        vec3 Tf = v3(m.Tf[0], m.Tf[1], m.Tf[2]);
+        p.col = p.col * exp3((-Tf) * p.dist * m.Density);    // :868
+        p.applyAbs = false;
+    } else if (w == 4) {
+    } else {
+        p.col = p.col * (w == 2 ? v3(m.Ks[0], m.Ks[1], m.Ks[2]) : v3(m.Kd[0], m.Kd[1], m.Kd[2]));   // :873
+    }
+    return !((float)p.bounce < fc.MAX_BOUNCES);               // loop condition :820
+}
+
+}  // namespace ptd

@@ -1,0 +1,923 @@
+// pt_hip.hip — wavefront path tracer for MI355X (gfx950) behind the C ABI of include/pt_api.h.
+//
+// Restates the per-pixel Monte-Carlo loop of the reference's fragment shader
+// (/root/reference/src/shaders/frag.glsl:884-934) as a wavefront state machine:
+//
+//   k_frame_setup   uniform work hoisted out of the per-pixel loop: rotationMatrix(ROTATION)
+//                   (:271-283) and the auto-focus ray (:901-906, identical for every pixel)
+//   k_generate      fills the path pool: job -> pixel, rngState = index + u_seed (:896), first
+//                   camera ray (:899-908), trace() prologue (:811-818)
+//   k_extend        rayScene (:548-653): per-object BVH traversal + ellipsoids, LDS-staged top of
+//                   the BVH, per-lane traversal stack in LDS        [the hot kernel]
+//   k_shade         trace() loop body (:823-879): material, index stack, chooseRay, absorption,
+//                   emission, cut-off, throughput; sky on miss; sample end -> regenerate the next
+//                   sample of the pixel-frame in place (serial rngState) or pull a
+//                   new job with one wave-aggregated atomic; finished pixel-frames go to `colbuf`
+//   k_compact       wave64 ballot/prefix-sum stream compaction of the live path slots (tail)
+//   k_accumulate    FRAME accumulation (:924-933) in u_frameCount order -> bit-identical to
+//                   frame-at-a-time rendering
+//
+// Path state is structure-of-arrays in float4 groups (16 B per lane per access = 1 KiB per wave
+// instruction, fully coalesced).  No MFMA: the path is divergent scalar fp32 + pointer chasing.
+#include "../../../include/pt_api.h"
+#include "pt_device.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ptd;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(x)                                                                                         \
+    do {                                                                                                   \
+        hipError_t e_ = (x);                                                                               \
+        if (e_ != hipSuccess) return fail(PT_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+constexpr int BLOCK = 256;
+constexpr int TILE_W = 32, TILE_H = 8;
+
+struct FrameIn { float params[12]; float origin[3]; float rotation[3]; float mouse[3]; };
+
+struct Control {            // device-resident scheduler words
+    unsigned nextJob;       // next unassigned job
+    int nAlive;             // live path slots
+    unsigned nQueue;        // compaction output cursor
+    unsigned pad;
+    unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
+};
+
+struct State {              // SoA path pool, float4 groups (see header comment)
+    float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *S1, *S2, *H;
+};
+
+struct Batch {
+    int W, H, nLocal, nSlots, shardCount;
+    unsigned nJobs;
+    int firstFrame, nFrames;
+    const int* seeds;         // device, nFrames
+    const int* pixList;       // device, nLocal: global pixel index in tile-major job order
+    float4* colbuf;           // nFrames * nSlots
+};
+
+// ------------------------------------------------------------------------------------------------ kernels
+
+__global__ void k_frame_setup(DevScene sc, const FrameIn* in, FrameConst* fc, EllipRec* ellip) {
+    __shared__ int stk[64];
+    if (threadIdx.x != 0) return;
+    const float* P = in->params;
+    fc->screenSize = P[0]; fc->focalLength = P[1]; fc->resolution = P[2]; fc->screenHratio = P[3]; fc->SAMPLE_RES = P[4];
+    fc->MAX_BOUNCES = P[5]; fc->BLUR = P[7]; fc->FOCAL_DISTANCE = P[8]; fc->AUTO_FOCUS = P[11];
+    for (int k = 0; k < 3; k++) { fc->origin[k] = in->origin[k]; fc->rotation[k] = in->rotation[k]; fc->mouse[k] = in->mouse[k]; }
+    auto rotM = [](float ax, float ay, float az, float* M) {      // rotateX * rotateY * (z != 0 ? rotateZ : I), row-major
+        float cx = cos_(ax), sx = sin_(ax), cy = cos_(ay), sy = sin_(ay);
+        float RX[9] = {1, 0, 0, 0, cx, sx, 0, -sx, cx};
+        float RY[9] = {cy, 0, -sy, 0, 1, 0, sy, 0, cy};
+        float RZ[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (az != 0.0f) { float cz = cos_(az), sz = sin_(az); RZ[0] = cz; RZ[1] = sz; RZ[3] = -sz; RZ[4] = cz; }
+        float T[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[3 * i + j] = RX[3 * i] * RY[j] + RX[3 * i + 1] * RY[3 + j] + RX[3 * i + 2] * RY[6 + j];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = T[3 * i] * RZ[j] + T[3 * i + 1] * RZ[3 + j] + T[3 * i + 2] * RZ[6 + j];
+    };
+    rotM(in->rotation[0], in->rotation[1], in->rotation[2], fc->camRot);
+    for (int i = 0; i < sc.numEllip; i++) {
+        EllipRec& E = ellip[i];
+        float rx = E.rot[0], ry = E.rot[1], rz = E.rot[2];
+        E.rotated = length(v3(rx, ry, rz)) > 0.0f ? 1 : 0;       // frag.glsl:613
+        if (E.rotated) {
+            float cx = cos_(rx), sx = sin_(rx), cy = cos_(ry), sy = sin_(ry), cz = cos_(rz), sz = sin_(rz);
+            float c0[3] = {cy * cz, cx * sz + cz * sx * sy, sx * sz - cx * cz * sy};      // rotateBack columns, :291-295
+            float c1[3] = {-cy * sz, cx * cz - sx * sy * sz, cz * sx + cx * sy * sz};
+            float c2[3] = {sy, -cy * sx, cx * cy};
+            for (int r = 0; r < 3; r++) { E.RB[3 * r] = c0[r]; E.RB[3 * r + 1] = c1[r]; E.RB[3 * r + 2] = c2[r]; }
+            rotM(rx, ry, rz, E.R);
+        }
+    }
+    __threadfence();
+    float mid = -1.0f;
+    if (fc->AUTO_FOCUS == 1.0f) {                                  // :901-906
+        DevScene s2 = sc; s2.ldsNodes = 0; s2.ldsTris = 0; s2.ellip = ellip;
+        vec3 fwd = vecmat(v3(0.0f, 0.0f, 1.0f), fc->camRot);
+        float t, u, v; int prim; Counters c;
+        intersectScene<false>(s2, v3(in->origin[0], in->origin[1], in->origin[2]), fwd, stk, 1, nullptr, nullptr, t, u, v, prim, c);
+        mid = (t < 1e25f) ? t : -1.0f;                             // result.distance (:641,:651)
+    }
+    fc->midToScene = mid;
+    fc->focus = (fc->AUTO_FOCUS == 1.0f && mid > 0.0f) ? mid : fc->FOCAL_DISTANCE;
+}
+
+__device__ __forceinline__ void storePath(const State& st, unsigned i, const Path& p, bool trans) {
+    st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
+    st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
+    st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.job));
+    st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f);
+    st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, 0.0f);
+    if (trans) {
+        st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
+        st.S0[i] = make_float4(p.s[0], p.s[1], p.s[2], p.s[3]);
+        st.S1[i] = make_float4(p.s[4], p.s[5], p.s[6], p.s[7]);
+        st.S2[i] = make_float4(p.s[8], p.s[9], 0.0f, 0.0f);
+    }
+}
+
+// A new pixel-frame job (one fragment-shader invocation): fresh "globals" (SURVEY.md Q-1), rngState = index + u_seed.
+__device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, unsigned job, Path& p) {
+    unsigned fi = job / (unsigned)b.nLocal, k = job - fi * (unsigned)b.nLocal;
+    int gp = b.pixList[k];
+    int px = gp % b.W, py = gp / b.W;
+    uint32_t index;
+    pixelIndex(fc, b.W, b.H, px, py, index);
+    p.job = job;
+    p.rng = index + (uint32_t)b.seeds[fi];
+    p.sum = v3(0.0f);
+    p.sample = 0;
+    p.applyAbs = false; p.inObj = false;
+    p.enter = v3(0.0f); p.dist = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 10; i++) p.s[i] = 0.0f;
+    p.stackSize = 0;
+    p.alive = true;
+    startSample(fc, b.W, b.H, px, py, p);
+}
+
+template <bool TRANS>
+__global__ void __launch_bounds__(BLOCK) k_generate(Batch b, const FrameConst* fcp, State st, int nSlots, Control* ctl) {
+    unsigned i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (unsigned)nSlots) return;
+    const FrameConst& fc = *fcp;
+    Path p;
+    if (i < b.nJobs) {
+        startJob(b, fc, i, p);
+    } else {
+        p = Path();
+        p.alive = false; p.job = 0; p.rng = 0; p.bounce = 0; p.sample = 0; p.stackSize = 0; p.inObj = false; p.applyAbs = false;
+        p.O = p.D = p.col = p.inc = p.sum = p.enter = v3(0.0f); p.dist = 0.0f;
+        for (int k = 0; k < 10; k++) p.s[k] = 0.0f;
+    }
+    storePath(st, i, p, TRANS);
+    st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
+}
+
+// rayScene for every live path slot.  Dynamic LDS: [nodes 4*ldsNodes float4][tris 3*ldsTris float4][stack depth*BLOCK int]
+template <bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const unsigned* queue, const unsigned* nQueue, int nSlots, Control* ctl) {
+    extern __shared__ float4 smem[];
+    float4* ldsN = smem;
+    float4* ldsT = smem + 4 * sc.ldsNodes;
+    int* stkBase = reinterpret_cast<int*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris);
+    unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    if (blockIdx.x * BLOCK >= n) return;                       // whole block beyond the live range
+    for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += BLOCK) ldsN[k] = sc.nodes[k];
+    for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += BLOCK) ldsT[k] = sc.tris[k];
+    __syncthreads();
+    unsigned q = blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= n) return;
+    unsigned i = queue ? queue[q] : q;
+    float4 g0 = st.G0[i], g1 = st.G1[i];
+    if (!(__float_as_uint(g1.w) & FL_ALIVE)) return;
+    float t, u, v; int prim; Counters c;
+    intersectScene<COUNT>(sc, v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), stkBase + threadIdx.x, BLOCK, ldsN, ldsT, t, u, v, prim, c);
+    st.H[i] = make_float4(t, u, v, __int_as_float(prim));
+    if (COUNT) {
+        atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
+        atomicAdd(&ctl->cnt[PT_CNT_TRITESTS], (unsigned long long)c.tritests);
+        atomicAdd(&ctl->cnt[PT_CNT_HITUPD], (unsigned long long)c.hitupd);
+        atomicAdd(&ctl->cnt[PT_CNT_BOXTESTS], (unsigned long long)c.boxtests);
+    }
+}
+
+// trace() loop body + sample/job bookkeeping for every live path slot
+template <bool TRANS>
+__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
+                                                 int nSlots, Control* ctl) {
+    unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    unsigned q = blockIdx.x * BLOCK + threadIdx.x;
+    bool valid = q < n;
+    unsigned i = valid ? (queue ? queue[q] : q) : 0;
+    const FrameConst& fc = *fcp;
+    Path p;
+    float4 g1 = valid ? st.G1[i] : make_float4(0, 0, 0, 0);
+    unpackFlags(p, __float_as_uint(g1.w));
+    bool live = valid && p.alive;
+    bool jobDone = false;
+    unsigned nSeg = 0, nSamp = 0;
+    if (live) {
+        float4 g0 = st.G0[i], g2 = st.G2[i], g3 = st.G3[i], g4 = st.G4[i], h = st.H[i];
+        p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
+        p.col = v3(g2.x, g2.y, g2.z); p.job = __float_as_uint(g2.w);
+        p.inc = v3(g3.x, g3.y, g3.z); p.sum = v3(g4.x, g4.y, g4.z);
+        if (TRANS) {
+            float4 g5 = st.G5[i], s0 = st.S0[i], s1 = st.S1[i], s2 = st.S2[i];
+            p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w;
+            p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
+        } else {
+            p.enter = v3(0.0f); p.dist = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 10; k++) p.s[k] = 0.0f;
+        }
+        nSeg = 1;
+        bool sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w));
+        if (sampleDone) {
+            p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
+            p.sample++;
+            nSamp = 1;
+            if ((float)p.sample < fc.SAMPLE_RES) {                 // loop condition :898
+                unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
+                int gp = b.pixList[k];
+                startSample(fc, b.W, b.H, gp % b.W, gp / b.W, p);
+            } else {
+                unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
+                unsigned ls = (b.shardCount == 1) ? (unsigned)b.pixList[k] : k;
+                float sr = fc.SAMPLE_RES;
+                b.colbuf[(size_t)fi * b.nSlots + ls] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
+                jobDone = true;
+            }
+        }
+    }
+    // wave-aggregated job pull: one atomic per wave
+    unsigned long long mask = __ballot(jobDone);
+    if (mask) {
+        int lane = threadIdx.x & 63;
+        int leader = __ffsll((long long)mask) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&ctl->nextJob, (unsigned)__popcll(mask));
+        base = __shfl(base, leader);
+        if (jobDone) {
+            unsigned job = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            if (job < b.nJobs) startJob(b, fc, job, p);
+            else p.alive = false;
+        }
+        unsigned long long dead = __ballot(jobDone && !p.alive);
+        if (dead && lane == leader) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
+    }
+    if (live) storePath(st, i, p, TRANS);
+    // statistics: one atomic per wave
+    unsigned long long lm = __ballot(live);
+    if (lm) {
+        unsigned long long sm = __ballot(nSamp != 0);
+        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)lm) - 1)) {
+            atomicAdd(&ctl->cnt[PT_CNT_SEGMENTS], (unsigned long long)__popcll(lm));
+            if (sm) atomicAdd(&ctl->cnt[PT_CNT_SAMPLES], (unsigned long long)__popcll(sm));
+        }
+    }
+}
+
+// wave64 ballot + prefix-sum (mbcnt) stream compaction of live slot indices: one atomic per wave
+__global__ void __launch_bounds__(BLOCK) k_compact(State st, const unsigned* inQueue, const unsigned* nIn, int nSlots, unsigned* outQueue, Control* ctl) {
+    unsigned n = inQueue ? *nIn : (unsigned)nSlots;
+    unsigned q = blockIdx.x * BLOCK + threadIdx.x;
+    bool valid = q < n;
+    unsigned i = valid ? (inQueue ? inQueue[q] : q) : 0;
+    bool live = valid && (__float_as_uint(st.G1[i].w) & FL_ALIVE);
+    unsigned long long mask = __ballot(live);
+    if (!mask) return;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&ctl->nQueue, (unsigned)__popcll(mask));
+    base = __shfl(base, leader);
+    if (live) outQueue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = i;
+}
+
+// FRAME accumulation, frag.glsl:924-933, over this batch's frames in u_frameCount order
+__global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst* fcp, float4* frame) {
+    unsigned ls = blockIdx.x * BLOCK + threadIdx.x;
+    if (ls >= (unsigned)b.nSlots) return;
+    int gp;
+    if (b.shardCount == 1) gp = (int)ls;
+    else { if (ls >= (unsigned)b.nLocal) return; gp = b.pixList[ls]; }
+    const FrameConst& fc = *fcp;
+    if (inMouseOverlay(fc, gp % b.W, gp / b.W)) return;
+    float4 F = frame[ls];
+    for (int f = 0; f < b.nFrames; f++) {
+        float4 c = b.colbuf[(size_t)f * b.nSlots + ls];
+        if ((float)(b.firstFrame + f) == 1.0f) F = make_float4(c.x, c.y, c.z, 1.0f);
+        else F = make_float4(F.x + c.x, F.y + c.y, F.z + c.z, F.w + 1.0f);
+    }
+    frame[ls] = F;
+}
+
+__global__ void k_unshard(const float4* gathered, const int* maps, int nSlots, int shardCount, float4* full) {
+    size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= (size_t)nSlots * shardCount) return;
+    int gp = maps[k];
+    if (gp >= 0) full[gp] = gathered[k];
+}
+
+__global__ void k_init_control(Control* ctl, unsigned nextJob, int nAlive) { ctl->nextJob = nextJob; ctl->nAlive = nAlive; ctl->nQueue = 0; }
+__global__ void k_zero_queue_cursor(Control* ctl) { ctl->nQueue = 0; }
+__global__ void k_copy_queue_count(const Control* ctl, unsigned* nQueueOut) { *nQueueOut = ctl->nQueue; }
+
+__global__ void k_debug_math(int fn, const float* x, const float* y, float* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (fn) {
+        case 0: r = sin_(x[i]); break;
+        case 1: r = cos_(x[i]); break;
+        case 2: r = log_(x[i]); break;
+        case 3: r = exp_(x[i]); break;
+        case 4: r = atan2_(x[i], y[i]); break;
+        case 5: r = asin_(x[i]); break;
+        default: r = __builtin_nanf("");
+    }
+    out[i] = r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ host side
+
+struct pt_ctx {
+    int device = 0, W = 0, H = 0, shardRank = 0, shardCount = 1;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    // raw SSBO contents (host copies, glBufferData semantics)
+    std::vector<float> origin, rotation, mouse, tris, params, imp, ellip, bvhdata, mtl;
+    std::vector<int32_t> bvhtree, leaftris, objidx;
+    std::vector<uint8_t> sky; int skyW = 0, skyH = 0;
+    bool sceneDirty = true, frameInDirty = true;
+    bool trans = false;
+    int stackDepth = 1;
+    // device scene
+    float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
+    uchar4* dSky = nullptr;
+    DevScene sc{};
+    // shard
+    std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; int* dAllMaps = nullptr;
+    float4* dFrame = nullptr;
+    // path pool
+    int poolSlots = 1 << 20; int allocSlots = 0; bool allocTrans = false;
+    State st{};
+    unsigned *dQueueA = nullptr, *dQueueB = nullptr, *dNQueue = nullptr;
+    float4* dColbuf = nullptr; size_t colbufElems = 0;
+    int* dSeeds = nullptr; int seedsCap = 0;
+    FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
+    int* hAlive = nullptr;          // pinned
+    FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr; int hSeedsCap = 0;   // pinned staging
+    // options / stats
+    bool countStats = false, timing = false;
+    int ldsBudget = 20 * 1024;
+    int compactBelowPct = 70;       // compact the queue when fewer than this % of the launched lanes are live
+    uint64_t hostCnt[PT_CNT_N] = {0};
+    struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; } kt[4];
+};
+
+namespace {
+
+int uploadVec(void** dptr, const void* src, size_t bytes, hipStream_t s) {
+    if (*dptr) { HIP_TRY(hipFree(*dptr)); *dptr = nullptr; }
+    if (bytes == 0) bytes = 16;
+    HIP_TRY(hipMalloc(dptr, bytes));
+    if (src) HIP_TRY(hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// tile-major enumeration of the pixels owned by `rank`
+void shardPixels(int W, int H, int rank, int count, std::vector<int32_t>& out) {
+    out.clear();
+    int ntx = (W + TILE_W - 1) / TILE_W, nty = (H + TILE_H - 1) / TILE_H;
+    for (int t = rank; t < ntx * nty; t += count) {
+        int tx = t % ntx, ty = t / ntx;
+        for (int y = ty * TILE_H; y < std::min(H, (ty + 1) * TILE_H); y++)
+            for (int x = tx * TILE_W; x < std::min(W, (tx + 1) * TILE_W); x++) out.push_back(y * W + x);
+    }
+}
+size_t shardSlots(int W, int H, int count) {
+    size_t mx = 0; std::vector<int32_t> tmp;
+    for (int r = 0; r < count; r++) { shardPixels(W, H, r, count, tmp); mx = std::max(mx, tmp.size()); }
+    return (mx + BLOCK - 1) / BLOCK * BLOCK;
+}
+
+// Validates the reference's buffers and builds the device-private layout (see pt_device.hpp).
+int buildScene(pt_ctx* c) {
+    size_t nTris = c->tris.size() / 40, nNodes = c->bvhtree.size() / 3;
+    if (c->params.size() < 12) return fail(PT_ERR_SCENE, "Parameters buffer (binding 4) must hold 12 floats");
+    if (c->origin.size() < 3 || c->rotation.size() < 3) return fail(PT_ERR_SCENE, "ORIGIN/ROTATION (bindings 0,1) not set");
+    if (c->mouse.size() < 3) return fail(PT_ERR_SCENE, "MOUSE_POS (binding 2) not set");
+    if (c->mtl.empty()) return fail(PT_ERR_SCENE, "mtlData (binding 14) not set");
+    if (c->objidx.empty()) return fail(PT_ERR_SCENE, "objIndices (binding 13) not set");
+    if (c->imp.empty() || (int)c->imp[0] != 0) return fail(PT_ERR_UNSUPPORTED, "implicit surfaces are dead code in the reference (rayImplicit returns 1e30, frag.glsl:385-386): send ImpData = [0]");
+    if (c->ellip.empty()) return fail(PT_ERR_SCENE, "EllipData (binding 7) not set");
+    if (c->sky.empty()) return fail(PT_ERR_SCENE, "texture 0 (sky) not set");
+    if (c->bvhdata.size() < 8 * nNodes) return fail(PT_ERR_SCENE, "BVHdata shorter than 8 floats per BVHtree node");
+    // materials
+    int me = (int)c->mtl[0];
+    if (me < 48) return fail(PT_ERR_SCENE, "mtlData[0] (floats per material) must be >= 48");
+    int nMat = (int)((c->mtl.size() - 1) / me);
+    std::vector<MatRec> mats(std::max(nMat, 1));
+    c->trans = false;
+    for (int m = 0; m < nMat; m++) {
+        const float* F = c->mtl.data() + (size_t)me * m;      // F[k] == mtlData[me*m + k]
+        static const int maps[] = {22, 23, 24, 32, 33, 34, 35, 37, 38, 39, 40, 41};
+        for (int k : maps) if ((int)F[k] > -1) return fail(PT_ERR_UNSUPPORTED, "material texture maps (map_* > -1) are not supported yet (SURVEY.md §8(f) N3)");
+        MatRec& r = mats[m];
+        for (int k = 0; k < 3; k++) { r.Kd[k] = F[4 + k]; r.Ks[k] = F[7 + k]; r.Tf[k] = F[13 + k]; r.Ke[k] = F[17 + k]; }
+        r.Tr = F[12]; r.Ni = F[16]; r.Density = F[20]; r.illum = (int)F[21]; r.Pm = F[25]; r.Pr = F[26]; r.Pc = F[28]; r.Pcr = F[29]; r.subsurface = F[42];
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        if (r.Tr > 0.0f || r.Tf[0] > 0.0f || r.illum == 5 || r.illum == 7) c->trans = true;
+    }
+    // objects / BVH
+    int numObj = c->objidx[0];
+    if (numObj < 0 || (size_t)numObj + 1 > c->objidx.size()) return fail(PT_ERR_SCENE, "objIndices[0] exceeds the buffer");
+    auto childOf = [&](int n, int side) { return c->bvhtree[3 * (size_t)n + 1 + side]; };
+    std::vector<int> newIdx(nNodes, -1), depth(nNodes, 0);
+    std::vector<int> order;                                     // inner nodes in multi-root BFS order
+    std::vector<char> seen(nNodes, 0);
+    std::vector<int> frontier;
+    auto isLeaf = [&](int n) { return (childOf(n, 0) | childOf(n, 1)) == -1; };   // bitwise OR, frag.glsl:478
+    for (int o = 0; o < numObj; o++) {
+        int r = c->objidx[1 + o];
+        if (r < 0 || (size_t)r >= nNodes) return fail(PT_ERR_SCENE, "objIndices root out of range");
+        if (seen[r]) return fail(PT_ERR_SCENE, "BVH node reachable twice (not a tree)");
+        seen[r] = 1; frontier.push_back(r);
+    }
+    int maxInnerDepth = -1;
+    {
+        std::vector<int> cur = frontier, nxt;
+        int d = 0;
+        while (!cur.empty()) {
+            nxt.clear();
+            for (int n : cur) {
+                depth[n] = d;
+                if (isLeaf(n)) continue;
+                maxInnerDepth = std::max(maxInnerDepth, d);
+                newIdx[n] = (int)order.size(); order.push_back(n);
+                for (int s = 0; s < 2; s++) {
+                    int ch = childOf(n, s);
+                    if (ch < 0 || (size_t)ch >= nNodes) return fail(PT_ERR_SCENE, "BVHtree child index out of range");
+                    if (seen[ch]) return fail(PT_ERR_SCENE, "BVH node reachable twice (not a tree)");
+                    seen[ch] = 1; nxt.push_back(ch);
+                }
+            }
+            cur.swap(nxt); d++;
+        }
+    }
+    int need = maxInnerDepth + 2;                               // worst-case entries on rayBVH's stack
+    if (need > 64) return fail(PT_ERR_SCENE, "BVH too deep for the reference's `int stack[64]` (frag.glsl:465)");
+    c->stackDepth = std::max(need, 1);
+    // leaf-ordered triangle records
+    std::vector<float4> triRecs; std::vector<int> leafRef(nNodes, REF_EMPTY);
+    auto f4 = [](float a, float b, float cc, float d) { return make_float4(a, b, cc, d); };
+    auto asf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    for (size_t n = 0; n < nNodes; n++) {
+        if (!seen[n] || !isLeaf((int)n)) continue;
+        int s = (int)c->bvhdata[8 * n + 6], e = (int)c->bvhdata[8 * n + 7];
+        if (e <= s) continue;                                   // empty leaf
+        if (s < 0 || (size_t)e > c->leaftris.size()) return fail(PT_ERR_SCENE, "leaf index range outside leafTriIndices");
+        leafRef[n] = -((int)(triRecs.size() / 3) + 1);
+        for (int i = s; i < e; i++) {
+            int t = c->leaftris[i];
+            if (t < 0 || (size_t)t >= nTris) return fail(PT_ERR_SCENE, "leafTriIndices entry outside the triangle buffer");
+            const float* T = c->tris.data() + 40 * (size_t)t;
+            int mat = (int)T[36];
+            if (mat < 0 || mat >= nMat) return fail(PT_ERR_SCENE, "triangle material index out of range (SURVEY.md Q-14: OBJ faces before any o/g line get -1)");
+            float e1x = T[4] - T[0], e1y = T[5] - T[1], e1z = T[6] - T[2], e2x = T[8] - T[0], e2y = T[9] - T[1], e2z = T[10] - T[2];
+            uint32_t idl = (uint32_t)t | (i == e - 1 ? 0x80000000u : 0u);
+            triRecs.push_back(f4(T[0], T[1], T[2], e1x)); triRecs.push_back(f4(e1y, e1z, e2x, e2y)); triRecs.push_back(f4(e2z, asf(idl), 0, 0));
+        }
+    }
+    auto refOf = [&](int n) { return isLeaf(n) ? leafRef[n] : newIdx[n]; };
+    std::vector<float4> nodeRecs;
+    for (int n : order) {
+        int L = childOf(n, 0), R = childOf(n, 1);
+        const float* A = c->bvhdata.data() + 8 * (size_t)L; const float* B = c->bvhdata.data() + 8 * (size_t)R;
+        nodeRecs.push_back(f4(A[0], A[1], A[2], A[3])); nodeRecs.push_back(f4(A[4], A[5], B[0], B[1])); nodeRecs.push_back(f4(B[2], B[3], B[4], B[5]));
+        nodeRecs.push_back(f4(asf((uint32_t)refOf(L)), asf((uint32_t)refOf(R)), 0, 0));
+    }
+    std::vector<ObjRoot> roots(std::max(numObj, 1));
+    for (int o = 0; o < numObj; o++) {
+        int r = c->objidx[1 + o]; const float* A = c->bvhdata.data() + 8 * (size_t)r;
+        for (int k = 0; k < 3; k++) { roots[o].bmin[k] = A[k]; roots[o].bmax[k] = A[3 + k]; }
+        roots[o].ref = refOf(r); roots[o].pad = 0;
+        // an empty root leaf would be "visited" by the reference and find nothing: it can simply never be pushed
+    }
+    std::vector<float4> shade(std::max<size_t>(nTris, 1) * 4);
+    for (size_t t = 0; t < nTris; t++) {
+        const float* T = c->tris.data() + 40 * t;
+        shade[4 * t] = f4(T[12], T[13], T[14], T[16]); shade[4 * t + 1] = f4(T[17], T[18], T[24], T[25]);
+        shade[4 * t + 2] = f4(T[28], T[29], T[32], asf((uint32_t)(int)T[36])); shade[4 * t + 3] = f4(T[33], 0, 0, 0);
+    }
+    // ellipsoids (frag.glsl:606-611 layout)
+    int nE = (int)c->ellip[0];
+    if (nE < 0 || c->ellip.size() < (size_t)1 + 11 * (size_t)nE) return fail(PT_ERR_SCENE, "EllipData shorter than its count says");
+    std::vector<EllipRec> er(std::max(nE, 1));
+    for (int i = 0; i < nE; i++) {
+        const float* E = c->ellip.data();
+        EllipRec& r = er[i]; std::memset(&r, 0, sizeof(r));
+        for (int k = 0; k < 3; k++) { r.c[k] = E[1 + 3 * i + k]; r.st[k] = E[1 + nE * 3 + 3 * i + k]; r.rot[k] = E[1 + nE * 6 + 3 * i + k]; }
+        r.r = E[1 + nE * 9 + i]; r.mat = (int)E[1 + nE * 10 + i];
+        if (r.mat < 0 || r.mat >= nMat) return fail(PT_ERR_SCENE, "ellipsoid material index out of range");
+    }
+    // upload
+    hipStream_t s = c->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    int rc;
+    if ((rc = uploadVec((void**)&c->dNodes, nodeRecs.data(), nodeRecs.size() * 16, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dTris, triRecs.data(), triRecs.size() * 16, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dShade, shade.data(), shade.size() * 16, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dRoots, roots.data(), roots.size() * sizeof(ObjRoot), s))) return rc;
+    if ((rc = uploadVec((void**)&c->dEllip, er.data(), er.size() * sizeof(EllipRec), s))) return rc;
+    if ((rc = uploadVec((void**)&c->dMats, mats.data(), mats.size() * sizeof(MatRec), s))) return rc;
+    if ((rc = uploadVec((void**)&c->dSky, c->sky.data(), c->sky.size(), s))) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    DevScene& sc = c->sc;
+    sc.nodes = c->dNodes; sc.nNodes = (int)order.size(); sc.tris = c->dTris; sc.nTriRecs = (int)(triRecs.size() / 3);
+    sc.shade = c->dShade; sc.nTris = (int)nTris; sc.roots = c->dRoots; sc.numObj = numObj; sc.ellip = c->dEllip; sc.numEllip = nE;
+    sc.mats = c->dMats; sc.numMat = nMat; sc.sky = c->dSky; sc.skyW = c->skyW; sc.skyH = c->skyH;
+    // LDS tile: as many leading (top-of-tree) node records and triangle records as the budget allows
+    int budget = c->ldsBudget - c->stackDepth * BLOCK * 4;
+    int ln = 0, lt = 0;
+    if (budget > 0) {
+        ln = std::min(sc.nNodes, budget / 64);
+        int rest = budget - ln * 64;
+        lt = std::min(sc.nTriRecs, rest / 48);
+        if (ln < sc.nNodes) lt = std::min(lt, 0);               // triangles only once every node fits
+    }
+    sc.ldsNodes = ln; sc.ldsTris = lt;
+    c->sceneDirty = false;
+    return 0;
+}
+
+int ensurePool(pt_ctx* c) {
+    if (c->allocSlots == c->poolSlots && c->allocTrans == c->trans) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H};
+    for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
+    for (unsigned** q : {&c->dQueueA, &c->dQueueB}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
+    size_t n = (size_t)c->poolSlots;
+    for (int k = 0; k < 10; k++) {
+        bool transOnly = (k >= 5 && k <= 8);
+        if (transOnly && !c->trans) continue;
+        HIP_TRY(hipMalloc((void**)groups[k], n * 16));
+    }
+    HIP_TRY(hipMalloc((void**)&c->dQueueA, n * 4));
+    HIP_TRY(hipMalloc((void**)&c->dQueueB, n * 4));
+    c->allocSlots = c->poolSlots; c->allocTrans = c->trans;
+    return 0;
+}
+
+int nextEventPair(pt_ctx::KT& k) {
+    if (k.used == k.ev.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+        k.ev.emplace_back(a, b);
+    }
+    return (int)k.used++;
+}
+#define TIMED_LAUNCH(kidx, ...)                                          \
+    do {                                                                 \
+        int ev_ = c->timing ? nextEventPair(c->kt[kidx]) : -1;          \
+        if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].first, s);      \
+        __VA_ARGS__;                                                     \
+        if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].second, s);     \
+    } while (0)
+
+int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
+    if (nFrames < 1) return fail(PT_ERR_ARG, "n_frames must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc;
+    if (c->sceneDirty && (rc = buildScene(c))) return rc;
+    // parameter checks (scope: SURVEY.md §2)
+    const float* P = c->params.data();
+    if (P[9] != 1.0f) return fail(PT_ERR_UNSUPPORTED, "RAYTRACING == 0 (directDiffuse, frag.glsl:655-681) is out of scope (SURVEY.md §8(f) N2)");
+    if (P[10] != 0.0f) return fail(PT_ERR_UNSUPPORTED, "DEBUG traversal heat-map (frag.glsl:539-547) is out of scope");
+    if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
+    if (!(P[4] >= 1.0f) || P[4] > 255.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,255]");
+    if (!(P[5] > 0.0f) || P[5] > 255.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,255]");
+    size_t nJobs64 = (size_t)c->nLocal * (size_t)nFrames;
+    if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
+    if ((rc = ensurePool(c))) return rc;
+    // per-batch inputs
+    if (c->seedsCap < nFrames) { if (c->dSeeds) HIP_TRY(hipFree(c->dSeeds)); HIP_TRY(hipMalloc((void**)&c->dSeeds, (size_t)nFrames * 4)); c->seedsCap = nFrames; }
+    if (c->hSeedsCap < nFrames) { if (c->hSeeds) HIP_TRY(hipHostFree(c->hSeeds)); HIP_TRY(hipHostMalloc((void**)&c->hSeeds, (size_t)nFrames * 4, hipHostMallocDefault)); c->hSeedsCap = nFrames; }
+    std::memcpy(c->hSeeds, seeds, (size_t)nFrames * 4);
+    HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)nFrames * 4, hipMemcpyHostToDevice, s));
+    size_t needCol = (size_t)nFrames * (size_t)c->nSlotsImg;
+    if (c->colbufElems < needCol) { if (c->dColbuf) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(c->dColbuf)); } HIP_TRY(hipMalloc((void**)&c->dColbuf, needCol * 16)); c->colbufElems = needCol; }
+    FrameIn& fin = *c->hFrameIn;
+    std::memcpy(fin.params, P, 48); std::memcpy(fin.origin, c->origin.data(), 12); std::memcpy(fin.rotation, c->rotation.data(), 12); std::memcpy(fin.mouse, c->mouse.data(), 12);
+    HIP_TRY(hipMemcpyAsync(c->dFrameIn, c->hFrameIn, sizeof(FrameIn), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, s, c->sc, c->dFrameIn, c->dFc, c->dEllip);
+
+    Batch b;
+    b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount; b.nJobs = (unsigned)nJobs64;
+    b.firstFrame = firstFrame; b.nFrames = nFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.colbuf = c->dColbuf;
+    int N = c->poolSlots;
+    unsigned first = (unsigned)std::min<size_t>((size_t)N, nJobs64);
+    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first, (int)first);
+    int gridN = (N + BLOCK - 1) / BLOCK;
+    if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<true>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+    else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<false>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+
+    size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
+    const unsigned* queue = nullptr;         // nullptr: identity (all slots)
+    unsigned launched = first;               // lanes worth launching (upper bound on live lanes)
+    unsigned* qCur = c->dQueueA; unsigned* qNext = c->dQueueB;
+    int alive = (int)first;
+    uint64_t iters = 0;
+    const int CHECK = 8;
+    while (alive > 0) {
+        for (int k = 0; k < CHECK; k++) {
+            int grid = (int)((launched + BLOCK - 1) / BLOCK);
+            if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+            else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+            if (c->trans) TIMED_LAUNCH(1, hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+            else TIMED_LAUNCH(1, hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+            iters++;
+        }
+        HIP_TRY(hipMemcpyAsync(c->hAlive, &c->dCtl->nAlive, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        alive = *c->hAlive;
+        // tail: once job supply has run dry the pool thins out -> compact live slots into a dense queue
+        if (alive > 0 && (uint64_t)alive * 100 < (uint64_t)launched * (uint64_t)c->compactBelowPct) {
+            int grid = (int)((launched + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL(k_zero_queue_cursor, dim3(1), dim3(1), 0, s, c->dCtl);
+            hipLaunchKernelGGL(k_compact, dim3(grid), dim3(BLOCK), 0, s, c->st, queue, c->dNQueue, (int)launched, qNext, c->dCtl);
+            hipLaunchKernelGGL(k_copy_queue_count, dim3(1), dim3(1), 0, s, c->dCtl, c->dNQueue);
+            queue = qNext; std::swap(qCur, qNext);
+            launched = (unsigned)alive;      // k_compact wrote exactly `alive` entries
+        }
+    }
+    int gridA = (c->nSlotsImg + BLOCK - 1) / BLOCK;
+    TIMED_LAUNCH(3, hipLaunchKernelGGL(k_accumulate, dim3(gridA), dim3(BLOCK), 0, s, b, c->dFc, c->dFrame));
+    HIP_TRY(hipGetLastError());
+    c->hostCnt[PT_CNT_ITERATIONS] += iters;
+    c->hostCnt[PT_CNT_EXTEND_LAUNCHES] += iters;
+    return 0;
+}
+
+int resolveTimes(pt_ctx* c) {
+    for (auto& k : c->kt) {
+        for (size_t i = 0; i < k.used; i++) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, k.ev[i].first, k.ev[i].second));
+            k.ms += ms; k.launches++;
+        }
+        k.used = 0;
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+const char* pt_last_error(void) { return g_err.c_str(); }
+
+int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count) {
+    if (!out || width < 1 || height < 1 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(PT_ERR_ARG, "pt_create: bad argument");
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= nDev) return fail(PT_ERR_NO_DEVICE, "HIP device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    pt_ctx* c = new pt_ctx();
+    c->device = device; c->W = width; c->H = height; c->shardRank = shard_rank; c->shardCount = shard_count;
+    HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
+    c->stream = c->ownStream;
+    shardPixels(width, height, shard_rank, shard_count, c->pixList);
+    c->nLocal = (int)c->pixList.size();
+    c->nSlotsImg = shard_count == 1 ? width * height : (int)shardSlots(width, height, shard_count);
+    if (c->nLocal == 0) { delete c; return fail(PT_ERR_ARG, "this shard owns no pixels (more shards than tiles)"); }
+    HIP_TRY(hipMalloc((void**)&c->dPixList, (size_t)c->nLocal * 4));
+    HIP_TRY(hipMemcpy(c->dPixList, c->pixList.data(), (size_t)c->nLocal * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->dFrame, (size_t)c->nSlotsImg * 16));
+    HIP_TRY(hipMemset(c->dFrame, 0, (size_t)c->nSlotsImg * 16));
+    HIP_TRY(hipMalloc((void**)&c->dFrameIn, sizeof(FrameIn)));
+    HIP_TRY(hipMalloc((void**)&c->dFc, sizeof(FrameConst)));
+    HIP_TRY(hipMalloc((void**)&c->dCtl, sizeof(Control)));
+    HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
+    HIP_TRY(hipMalloc((void**)&c->dNQueue, 4));
+    HIP_TRY(hipHostMalloc((void**)&c->hAlive, 4, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->hFrameIn, sizeof(FrameIn), hipHostMallocDefault));
+    c->imp = {0.0f}; c->ellip = {0.0f}; c->objidx = {0};
+    c->mouse = {-1.0e6f, -1.0e6f, 0.0f};
+    *out = c;
+    return PT_OK;
+}
+
+int pt_destroy(pt_ctx* c) {
+    if (!c) return PT_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
+                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl};
+    for (void* p : ptrs) if (p) hipFree(p);
+    if (c->hAlive) hipHostFree(c->hAlive);
+    if (c->hFrameIn) hipHostFree(c->hFrameIn);
+    if (c->hSeeds) hipHostFree(c->hSeeds);
+    for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+    return PT_OK;
+}
+
+int pt_set_buffer(pt_ctx* c, int binding, const void* data, size_t bytes) {
+    if (!c || (!data && bytes)) return fail(PT_ERR_ARG, "pt_set_buffer: null argument");
+    if (bytes % 4) return fail(PT_ERR_ARG, "pt_set_buffer: size must be a multiple of 4 bytes");
+    const float* f = static_cast<const float*>(data); const int32_t* i = static_cast<const int32_t*>(data); size_t n = bytes / 4;
+    switch (binding) {
+        case PT_BIND_ORIGIN: if (n < 3) return fail(PT_ERR_ARG, "ORIGIN needs 3 floats"); c->origin.assign(f, f + 3); return PT_OK;      // per-frame glBufferSubData: no scene rebuild
+        case PT_BIND_ROTATION: if (n < 3) return fail(PT_ERR_ARG, "ROTATION needs 3 floats"); c->rotation.assign(f, f + 3); return PT_OK;
+        case PT_BIND_MOUSE: if (n < 3) return fail(PT_ERR_ARG, "MOUSE_POS needs 3 floats"); c->mouse.assign(f, f + 3); return PT_OK;
+        case PT_BIND_PARAMS: if (n < 12) return fail(PT_ERR_ARG, "Parameters needs 12 floats"); c->params.assign(f, f + 12); return PT_OK;
+        case PT_BIND_TRIANGLES: if (n % 40) return fail(PT_ERR_ARG, "triangle buffer must be 40 floats per triangle"); c->tris.assign(f, f + n); break;
+        case PT_BIND_IMPLICITS: c->imp.assign(f, f + n); break;
+        case PT_BIND_ELLIPSOIDS: c->ellip.assign(f, f + n); break;
+        case PT_BIND_BVHDATA: c->bvhdata.assign(f, f + n); break;
+        case PT_BIND_BVHTREE: if (n % 3) return fail(PT_ERR_ARG, "BVHtree must be 3 ints per node"); c->bvhtree.assign(i, i + n); break;
+        case PT_BIND_LEAFTRIS: c->leaftris.assign(i, i + n); break;
+        case PT_BIND_OBJINDICES: c->objidx.assign(i, i + n); break;
+        case PT_BIND_MATERIALS: c->mtl.assign(f, f + n); break;
+        default: return fail(PT_ERR_ARG, "pt_set_buffer: binding point not consumed by the render path (frag.glsl declares 0-5,7,10-15)");
+    }
+    c->sceneDirty = true;
+    return PT_OK;
+}
+
+int pt_set_texture(pt_ctx* c, int index, int w, int h, const uint8_t* rgba8) {
+    if (!c || !rgba8 || w < 1 || h < 1) return fail(PT_ERR_ARG, "pt_set_texture: bad argument");
+    if (index != 0) return fail(PT_ERR_UNSUPPORTED, "only texture 0 (sky) is read by the render path; material maps are SURVEY.md §8(f) N3");
+    c->sky.assign(rgba8, rgba8 + (size_t)w * h * 4); c->skyW = w; c->skyH = h; c->sceneDirty = true;
+    return PT_OK;
+}
+
+int pt_reset_frame(pt_ctx* c) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->dFrame, 0, (size_t)c->nSlotsImg * 16, c->stream));
+    return PT_OK;
+}
+
+int pt_render(pt_ctx* c, int frame_count, int seed) { if (!c) return fail(PT_ERR_ARG, "null context"); int32_t s = seed; return renderBatch(c, frame_count, 1, &s); }
+int pt_render_batch(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
+    if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch: null argument");
+    return renderBatch(c, first_frame, n_frames, seeds);
+}
+
+int pt_synchronize(pt_ctx* c) { if (!c) return fail(PT_ERR_ARG, "null context"); HIP_TRY(hipSetDevice(c->device)); HIP_TRY(hipStreamSynchronize(c->stream)); return PT_OK; }
+
+int pt_read_frame(pt_ctx* c, float* out) {
+    if (!c || !out) return fail(PT_ERR_ARG, "pt_read_frame: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->shardCount == 1) {
+        HIP_TRY(hipMemcpyAsync(out, c->dFrame, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return PT_OK;
+    }
+    std::vector<float> tmp((size_t)c->nLocal * 4);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), c->dFrame, tmp.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < c->nLocal; k++) std::memcpy(out + 4 * (size_t)c->pixList[k], tmp.data() + 4 * (size_t)k, 16);
+    return PT_OK;
+}
+
+int pt_frame_device(pt_ctx* c, void** dev_ptr, size_t* n_pixels) {
+    if (!c || !dev_ptr || !n_pixels) return fail(PT_ERR_ARG, "pt_frame_device: null argument");
+    *dev_ptr = c->dFrame; *n_pixels = (size_t)c->nSlotsImg;
+    return PT_OK;
+}
+
+int pt_shard_slots(int width, int height, int shard_count, size_t* n_slots) {
+    if (width < 1 || height < 1 || shard_count < 1 || !n_slots) return fail(PT_ERR_ARG, "pt_shard_slots: bad argument");
+    *n_slots = shard_count == 1 ? (size_t)width * height : shardSlots(width, height, shard_count);
+    return PT_OK;
+}
+
+int pt_shard_map(int width, int height, int shard_rank, int shard_count, int32_t* out, size_t n_slots) {
+    if (width < 1 || height < 1 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count || !out) return fail(PT_ERR_ARG, "pt_shard_map: bad argument");
+    std::vector<int32_t> px;
+    if (shard_count == 1) { for (size_t i = 0; i < n_slots; i++) out[i] = i < (size_t)width * height ? (int32_t)i : -1; return PT_OK; }
+    shardPixels(width, height, shard_rank, shard_count, px);
+    if (px.size() > n_slots) return fail(PT_ERR_ARG, "pt_shard_map: n_slots too small");
+    for (size_t i = 0; i < n_slots; i++) out[i] = i < px.size() ? px[i] : -1;
+    return PT_OK;
+}
+
+int pt_unshard(pt_ctx* c, const void* gathered_dev, void* full_dev) {
+    if (!c || !gathered_dev || !full_dev) return fail(PT_ERR_ARG, "pt_unshard: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t total = (size_t)c->nSlotsImg * c->shardCount;
+    if (!c->dAllMaps) {
+        std::vector<int32_t> maps(total);
+        for (int r = 0; r < c->shardCount; r++) { int rc = pt_shard_map(c->W, c->H, r, c->shardCount, maps.data() + (size_t)r * c->nSlotsImg, (size_t)c->nSlotsImg); if (rc) return rc; }
+        HIP_TRY(hipMalloc((void**)&c->dAllMaps, total * 4));
+        HIP_TRY(hipMemcpy(c->dAllMaps, maps.data(), total * 4, hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_unshard, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, (const float4*)gathered_dev, c->dAllMaps, c->nSlotsImg, c->shardCount, (float4*)full_dev);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+int pt_set_stream(pt_ctx* c, void* hip_stream) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
+    return PT_OK;
+}
+
+int pt_set_option(pt_ctx* c, int option, int64_t value) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    switch (option) {
+        case 0: if (value < BLOCK || value > (1 << 26)) return fail(PT_ERR_ARG, "path slots must be in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
+        case 1: c->countStats = value != 0; return PT_OK;
+        case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
+        case 3: c->compactBelowPct = (int)value; return PT_OK;
+    }
+    return fail(PT_ERR_ARG, "unknown option");
+}
+
+int pt_get_counters(pt_ctx* c, uint64_t* out, int n) {
+    if (!c || !out) return fail(PT_ERR_ARG, "pt_get_counters: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    Control h;
+    HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
+    uint64_t all[PT_CNT_N];
+    for (int k = 0; k < PT_CNT_N; k++) all[k] = c->hostCnt[k];
+    for (int k = 0; k <= PT_CNT_BOXTESTS; k++) all[k] = h.cnt[k];
+    for (int k = 0; k < n && k < PT_CNT_N; k++) out[k] = all[k];
+    return PT_OK;
+}
+
+int pt_reset_counters(pt_ctx* c) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
+    std::memset(c->hostCnt, 0, sizeof(c->hostCnt));
+    for (auto& k : c->kt) { k.used = 0; k.ms = 0; k.launches = 0; }
+    return PT_OK;
+}
+
+int pt_set_timing(pt_ctx* c, int enabled) { if (!c) return fail(PT_ERR_ARG, "null context"); c->timing = enabled != 0; return PT_OK; }
+
+int pt_kernel_time(pt_ctx* c, int kernel, int64_t* launches, double* total_ms) {
+    if (!c || kernel < 0 || kernel > 3 || !launches || !total_ms) return fail(PT_ERR_ARG, "pt_kernel_time: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = resolveTimes(c);
+    if (rc) return rc;
+    *launches = c->kt[kernel].launches; *total_ms = c->kt[kernel].ms;
+    return PT_OK;
+}
+
+int pt_debug_math(pt_ctx* c, int fn, const float* x, const float* y, float* out, size_t n) {
+    if (!c || !x || !out) return fail(PT_ERR_ARG, "pt_debug_math: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    float *dx, *dy, *dout;
+    HIP_TRY(hipMalloc((void**)&dx, n * 4)); HIP_TRY(hipMalloc((void**)&dy, n * 4)); HIP_TRY(hipMalloc((void**)&dout, n * 4));
+    HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+    if (y) HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice)); else HIP_TRY(hipMemset(dy, 0, n * 4));
+    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, fn, dx, dy, dout, n);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy); hipFree(dout);
+    return PT_OK;
+}
+
+int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, size_t n) {
+    if (!c || !o || !d || !out || n < 1 || n > (1u << 24)) return fail(PT_ERR_ARG, "pt_debug_intersect: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if (c->sceneDirty && (rc = buildScene(c))) return rc;
+    size_t np = (n + BLOCK - 1) / BLOCK * BLOCK;
+    std::vector<float> g0(np * 4, 0.0f), g1(np * 4, 0.0f);
+    for (size_t i = 0; i < n; i++) {
+        g0[4 * i] = o[3 * i]; g0[4 * i + 1] = o[3 * i + 1]; g0[4 * i + 2] = o[3 * i + 2]; g0[4 * i + 3] = d[3 * i];
+        g1[4 * i] = d[3 * i + 1]; g1[4 * i + 1] = d[3 * i + 2]; uint32_t fl = FL_ALIVE; std::memcpy(&g1[4 * i + 3], &fl, 4);
+    }
+    State st{};
+    HIP_TRY(hipMalloc((void**)&st.G0, np * 16)); HIP_TRY(hipMalloc((void**)&st.G1, np * 16)); HIP_TRY(hipMalloc((void**)&st.H, np * 16));
+    HIP_TRY(hipMemcpy(st.G0, g0.data(), np * 16, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(st.G1, g1.data(), np * 16, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(st.H, 0, np * 16));
+    // the ellipsoid rotation matrices are produced by k_frame_setup
+    FrameIn fin; std::memset(&fin, 0, sizeof(fin));
+    if (c->params.size() >= 12) std::memcpy(fin.params, c->params.data(), 48);
+    fin.params[11] = 0.0f;
+    HIP_TRY(hipMemcpy(c->dFrameIn, &fin, sizeof(fin), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, c->stream, c->sc, c->dFrameIn, c->dFc, c->dEllip);
+    size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
+    hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, c->dNQueue, (int)np, c->dCtl);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float> h(np * 4);
+    HIP_TRY(hipMemcpy(h.data(), st.H, np * 16, hipMemcpyDeviceToHost));
+    std::memcpy(out, h.data(), n * 16);
+    hipFree(st.G0); hipFree(st.G1); hipFree(st.H);
+    return PT_OK;
+}
+
+}  // extern "C"

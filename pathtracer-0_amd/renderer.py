@@ -1,0 +1,183 @@
+"""Render call of the reference behind the C ABI (include/pt_api.h), Python face.
+
+`Renderer` plays the part of the GL state the reference's frame loop drives
+(/root/reference/src/Main/dispatch.java:590-713): set_buffer == glBufferData/glBufferSubData on
+an SSBO binding point, set_texture == texture upload, reset_frame == resetTexture (:732-735),
+render(frame_count, seed) == glUniform1i x2 + glDrawArrays (:697-705), read_frame == glReadPixels
+of the RGBA32F accumulation image.  There is no CPU fallback: constructing a Renderer without
+the HIP library or without a gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "iterations", "extend_launches"]
+KERNELS = {"extend": 0, "shade": 1, "generate": 2, "accumulate": 3}
+OPTIONS = {"path_slots": 0, "count_stats": 1, "lds_budget": 2, "compact_below_pct": 3}
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libpt_hip.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: the HIP extension is required (no fallback). Build it with __graft_entry__.build()")
+        L = C.CDLL(path)
+        vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
+        L.pt_destroy.argtypes = [vp]
+        L.pt_set_buffer.argtypes = [vp, ci, vp, sz]
+        L.pt_set_texture.argtypes = [vp, ci, ci, ci, vp]
+        L.pt_reset_frame.argtypes = [vp]
+        L.pt_render.argtypes = [vp, ci, ci]
+        L.pt_render_batch.argtypes = [vp, ci, ci, vp]
+        L.pt_synchronize.argtypes = [vp]
+        L.pt_read_frame.argtypes = [vp, vp]
+        L.pt_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+        L.pt_shard_slots.argtypes = [ci, ci, ci, C.POINTER(sz)]
+        L.pt_shard_map.argtypes = [ci, ci, ci, ci, vp, sz]
+        L.pt_unshard.argtypes = [vp, vp, vp]
+        L.pt_set_stream.argtypes = [vp, vp]
+        L.pt_set_option.argtypes = [vp, ci, C.c_int64]
+        L.pt_get_counters.argtypes = [vp, vp, ci]
+        L.pt_reset_counters.argtypes = [vp]
+        L.pt_kernel_time.argtypes = [vp, ci, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.pt_set_timing.argtypes = [vp, ci]
+        L.pt_debug_math.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.pt_debug_intersect.argtypes = [vp, vp, vp, vp, sz]
+        _LIB = L
+    return _LIB
+
+
+class PtError(RuntimeError):
+    """Error code + message of the C ABI (the reference throws RuntimeException at these points)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+def _check(rc):
+    if rc != 0:
+        raise PtError(rc, lib().pt_last_error().decode())
+
+
+def shard_slots(W, H, count):
+    n = C.c_size_t()
+    _check(lib().pt_shard_slots(W, H, count, C.byref(n)))
+    return n.value
+
+
+def shard_map(W, H, rank, count):
+    n = shard_slots(W, H, count)
+    out = np.empty(n, dtype=np.int32)
+    _check(lib().pt_shard_map(W, H, rank, count, out.ctypes.data, n))
+    return out
+
+
+class Renderer:
+    def __init__(self, W, H, device=0, shard_rank=0, shard_count=1):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.W, self.H, self.shard_rank, self.shard_count = W, H, shard_rank, shard_count
+        _check(self._L.pt_create(C.byref(self._h), device, W, H, shard_rank, shard_count))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- SSBO / texture uploads -------------------------------------------------------------
+    def set_buffer(self, binding, array):
+        a = np.ascontiguousarray(array)
+        assert a.dtype in (np.float32, np.int32), "SSBO contents are float32 or int32"
+        _check(self._L.pt_set_buffer(self._h, int(binding), a.ctypes.data, a.nbytes))
+
+    def set_texture(self, index, rgba8):
+        a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 4
+        _check(self._L.pt_set_texture(self._h, int(index), a.shape[1], a.shape[0], a.ctypes.data))
+
+    def load_workload(self, wl):
+        for b, arr in wl.buffers.items():
+            self.set_buffer(b, arr)
+        self.set_texture(0, wl.sky)
+
+    # --- frame loop ---------------------------------------------------------------------------
+    def reset_frame(self):
+        _check(self._L.pt_reset_frame(self._h))
+
+    def render(self, frame_count, seed):
+        _check(self._L.pt_render(self._h, int(frame_count), int(seed)))
+
+    def render_batch(self, first_frame, seeds):
+        s = np.ascontiguousarray(seeds, dtype=np.int32)
+        _check(self._L.pt_render_batch(self._h, int(first_frame), int(s.size), s.ctypes.data))
+
+    def synchronize(self):
+        _check(self._L.pt_synchronize(self._h))
+
+    def read_frame(self, out=None):
+        if out is None:
+            out = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == self.W * self.H * 4
+        _check(self._L.pt_read_frame(self._h, out.ctypes.data))
+        return out
+
+    def frame_device(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self._L.pt_frame_device(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def unshard(self, gathered_ptr, full_ptr):
+        _check(self._L.pt_unshard(self._h, C.c_void_p(gathered_ptr), C.c_void_p(full_ptr)))
+
+    def set_stream(self, hip_stream):
+        _check(self._L.pt_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_option(self, name, value):
+        _check(self._L.pt_set_option(self._h, OPTIONS[name], int(value)))
+
+    # --- statistics ---------------------------------------------------------------------------
+    def counters(self):
+        out = np.zeros(len(COUNTERS), dtype=np.uint64)
+        _check(self._L.pt_get_counters(self._h, out.ctypes.data, len(COUNTERS)))
+        return dict(zip(COUNTERS, [int(x) for x in out]))
+
+    def reset_counters(self):
+        _check(self._L.pt_reset_counters(self._h))
+
+    def set_timing(self, on):
+        _check(self._L.pt_set_timing(self._h, 1 if on else 0))
+
+    def kernel_time(self, name):
+        n, ms = C.c_int64(), C.c_double()
+        _check(self._L.pt_kernel_time(self._h, KERNELS[name], C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    # --- parity probes --------------------------------------------------------------------------
+    def debug_math(self, fn, x, y=None):
+        names = {"sin": 0, "cos": 1, "log": 2, "exp": 3, "atan2": 4, "asin": 5}
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        yp = None if y is None else np.ascontiguousarray(y, dtype=np.float32).ctypes.data
+        _check(self._L.pt_debug_math(self._h, names[fn], x.ctypes.data, yp, out.ctypes.data, x.size))
+        return out
+
+    def debug_intersect(self, o, d):
+        o = np.ascontiguousarray(o, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((o.shape[0], 4), dtype=np.float32)
+        _check(self._L.pt_debug_intersect(self._h, o.ctypes.data, d.ctypes.data, out.ctypes.data, o.shape[0]))
+        return out[:, :3].copy(), out[:, 3].copy().view(np.int32)

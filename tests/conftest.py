@@ -1,0 +1,50 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import ptimport  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pt():
+    mod = ptimport.load()
+    from pathtracer_0_amd import build
+    build.build_host()
+    return mod
+
+
+@pytest.fixture(scope="session")
+def oracle(pt):
+    import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def renderer_mod(pt):
+    from pathtracer_0_amd import renderer
+    return renderer
+
+
+def frames_equal(a, b):
+    """bit-exact comparison that treats NaN == NaN"""
+    a = np.asarray(a); b = np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b) or \
+        np.array_equal(a, b, equal_nan=True)
+
+
+def rmse(a, b):
+    """per-pixel RMSE over rgb of FRAME.rgb / FRAME.a"""
+    ia = a[..., :3] / np.maximum(a[..., 3:4], 1e-30)
+    ib = b[..., :3] / np.maximum(b[..., 3:4], 1e-30)
+    return float(np.sqrt(np.mean((ia.astype(np.float64) - ib.astype(np.float64)) ** 2)))
