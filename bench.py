@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the wavefront path tracer on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one sample batch of the workload: `frames_per_step` frames x SAMPLE_RES samples/pixel
+over the whole W x H image (tile-sharded over the N ranks), ending with the single gather of the
+accumulated framebuffer on rank 0 (RCCL when N > 1).  Default workload C3 = BASELINE.json
+configs[2] (1920x1080, 8 bounces, glass + metal spheres: the configuration the metric
+"Msamples/s at 1920x1080x8-bounce" is quoted on; fits one GPU), 32 frames x 8 spp = 256 spp per
+step.  Inputs (scene, path pool, accumulators) are resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import ptimport  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+Q_EXTEND = 44              # algorithmic queue bytes per segment in the intersect kernel: read O,D (24) + write hit record (20), SURVEY.md §8(d)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--frames-per-step", type=int, default=None, help="frames (x SAMPLE_RES spp) per step; default = the config's full spp")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--path-slots", type=int, default=None)
+    ap.add_argument("--lds-budget", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pt = ptimport.load()
+    from pathtracer_0_amd import renderer, scenes, shard
+
+    cfg = scenes.CONFIGS[args.config]
+    W = args.width or cfg["W"]
+    H = args.height or cfg["H"]
+    sample_res = cfg["sample_res"]
+    fps = args.frames_per_step or cfg["spp"] // sample_res
+    spp_step = fps * sample_res
+    wl = scenes.build(args.config, W, H)
+
+    r = renderer.Renderer(W, H, device=local_rank, shard_rank=rank, shard_count=world)
+    if args.path_slots:
+        r.set_option("path_slots", args.path_slots)
+    if args.lds_budget is not None:
+        r.set_option("lds_budget", args.lds_budget)
+    stream = torch.cuda.Stream(dev)             # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+    r.load_workload(wl)
+    r.reset_frame()
+    packed = shard.frame_tensor(r, dev)
+    maps = torch.from_numpy(shard.all_maps(W, H, world, renderer.shard_map).astype(np.int64)).to(dev)
+
+    frame_no = [1]
+
+    def step():
+        first = frame_no[0]
+        seeds = [scenes.frame_seed(f) for f in range(first, first + fps)]
+        r.render_batch(first, seeds)
+        frame_no[0] += fps
+        return shard.gather_frame(packed, W, H, world, maps, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- untimed: statistics pass for the roofline (counters are deterministic per scene + seeds) ----
+    stats = None
+    if not args.no_roofline:
+        r.set_option("count_stats", 1)
+        r.reset_counters()
+        first = 1
+        nstat = min(fps, 2)
+        r.render_batch(first, [scenes.frame_seed(f) for f in range(first, first + nstat)])
+        r.synchronize()
+        stats = r.counters()
+        r.set_option("count_stats", 0)
+        r.reset_frame()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    r.reset_counters()
+    if not args.no_roofline:
+        r.set_timing(True)
+    t0 = time.perf_counter()
+    full = None
+    for _ in range(args.steps):
+        full = step()
+    fence()
+    dt = time.perf_counter() - t0
+    r.set_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples = float(W) * H * spp_step * args.steps
+    value = samples / dt / 1e6
+
+    out = {
+        "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {W}x{H}, {cfg['bounces']}-bounce, {spp_step} spp/step ({fps} frames x SAMPLE_RES {sample_res}), "
+                               f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs, tile-sharded over {world} GPU(s), 1 framebuffer gather per step",
+                   "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"]},
+    }
+
+    if stats is not None:
+        n_ext, ms_ext = r.kernel_time("extend")
+        n_sh, ms_sh = r.kernel_time("shade")
+        S = stats["segments"] / max(stats["samples"], 1)
+        seg = S * samples / world                       # segments this rank traced in the timed region (S from the statistics pass)
+        nv, tt, hu = stats["nodes"] / stats["segments"], stats["tritests"] / stats["segments"], stats["hitupd"] / stats["segments"]
+        bytes_per_seg_extend = Q_EXTEND + nv * 44 + tt * 36 + hu * 124
+        bytes_per_sample = S * 304 + S * (nv * 44 + tt * 36 + hu * 124) + 32.0 / sample_res
+        avg_ms = ms_ext / max(n_ext, 1)
+        bytes_per_launch = bytes_per_seg_extend * seg / max(n_ext, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                           "avg_launch_ms": round(avg_ms, 4), "launches": n_ext, "algorithmic_bytes_per_launch": round(bytes_per_launch),
+                           "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3), "bytes": round(bytes_per_seg_extend, 1)},
+                           "segments_per_sample": round(S, 3), "bytes_per_sample_whole_path": round(bytes_per_sample, 1),
+                           "whole_path_GBps": round(bytes_per_sample * value * 1e6 / 1e9 / world, 1),
+                           "shade_avg_launch_ms": round(ms_sh / max(n_sh, 1), 4), "extend_share_of_step": round(ms_ext / (dt * 1e3), 3),
+                           "shade_share_of_step": round(ms_sh / (dt * 1e3), 3)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the reference has no CPU render path: the timed CPU baseline is the oracle ("port")
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle
+        cores = min(os.cpu_count() or 1, 16)
+        sc = oracle.Scene.from_workload(wl)
+        xs = ys = 2 if W * H > 500000 else 1
+        buf = np.zeros((H, W, 4), dtype=np.float32)
+        tc = time.perf_counter()
+        _, ocnt = oracle.render(sc, W, H, 1, scenes.frame_seed(1), buf, nthreads=cores, xs=xs, ys=ys)
+        tcpu = time.perf_counter() - tc
+        csamp = float(ocnt[4])
+        out["cpu_baseline"] = {"value": round(csamp / tcpu / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle (C++ restatement of frag.glsl), frame 1 ({sample_res} spp) of the same workload at every {xs}th pixel in x and y: "
+                                         f"{int(csamp)} samples in {tcpu:.2f} s"}
+    if rank == 0:
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 }
 
 // trace() loop body + sample/job bookkeeping for every live path slot
-template <bool TRANS>
+template <bool TRANS, bool STATS>
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
                                                  int nSlots, Control* ctl) {
     unsigned n = queue ? *nQueue : (unsigned)nSlots;
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
     unpackFlags(p, __float_as_uint(g1.w));
     bool live = valid && p.alive;
     bool jobDone = false;
-    unsigned nSeg = 0, nSamp = 0;
+    unsigned nSamp = 0;
     if (live) {
         float4 g0 = st.G0[i], g2 = st.G2[i], g3 = st.G3[i], g4 = st.G4[i], h = st.H[i];
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
@@ -222,7 +222,6 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
 #pragma unroll
             for (int k = 0; k < 10; k++) p.s[k] = 0.0f;
         }
-        nSeg = 1;
         bool sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w));
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
@@ -241,28 +240,36 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
             }
         }
     }
-    // wave-aggregated job pull: one atomic per wave
+    // job pull: wave64 ballot + prefix count, aggregated once more over the block's 4 waves through LDS, so
+    // the scheduler word sees ONE atomic per 256 lanes per launch (a single address sustains only ~90 atomics/us)
+    __shared__ unsigned sCnt[BLOCK / 64];
+    __shared__ unsigned sBase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long mask = __ballot(jobDone);
-    if (mask) {
-        int lane = threadIdx.x & 63;
-        int leader = __ffsll((long long)mask) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(&ctl->nextJob, (unsigned)__popcll(mask));
-        base = __shfl(base, leader);
-        if (jobDone) {
-            unsigned job = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-            if (job < b.nJobs) startJob(b, fc, job, p);
-            else p.alive = false;
-        }
-        unsigned long long dead = __ballot(jobDone && !p.alive);
-        if (dead && lane == leader) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
+    if (lane == 0) sCnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) total += sCnt[w];
+        sBase = total ? atomicAdd(&ctl->nextJob, total) : 0u;
     }
+    __syncthreads();
+    if (jobDone) {
+        unsigned off = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) off += (w < wave) ? sCnt[w] : 0u;
+        unsigned job = sBase + off + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+        if (job < b.nJobs) startJob(b, fc, job, p);
+        else p.alive = false;
+    }
+    unsigned long long dead = __ballot(jobDone && !p.alive);
+    if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
     if (live) storePath(st, i, p, TRANS);
-    // statistics: one atomic per wave
-    unsigned long long lm = __ballot(live);
-    if (lm) {
+    if (STATS) {                                  // statistics (count mode only): one atomic per wave
+        unsigned long long lm = __ballot(live);
         unsigned long long sm = __ballot(nSamp != 0);
-        if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)lm) - 1)) {
+        if (lm && lane == (__ffsll((long long)lm) - 1)) {
             atomicAdd(&ctl->cnt[PT_CNT_SEGMENTS], (unsigned long long)__popcll(lm));
             if (sm) atomicAdd(&ctl->cnt[PT_CNT_SAMPLES], (unsigned long long)__popcll(sm));
         }
@@ -629,8 +636,9 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
             int grid = (int)((launched + BLOCK - 1) / BLOCK);
             if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
             else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
-            if (c->trans) TIMED_LAUNCH(1, hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
-            else TIMED_LAUNCH(1, hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+#define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl
+            if (c->trans) { if (c->countStats) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<true, true>), SHADE_ARGS)); else TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<true, false>), SHADE_ARGS)); }
+            else { if (c->countStats) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<false, true>), SHADE_ARGS)); else TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<false, false>), SHADE_ARGS)); }
             iters++;
         }
         HIP_TRY(hipMemcpyAsync(c->hAlive, &c->dCtl->nAlive, 4, hipMemcpyDeviceToHost, s));

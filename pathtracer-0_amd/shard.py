@@ -1,0 +1,51 @@
+"""Multi-GPU image sharding: one process per GPU, one RCCL collective per sample batch.
+
+Every pixel-frame lane is independent (shared read-only scene, RNG keyed on the GLOBAL pixel
+index, /root/reference/src/shaders/frag.glsl:886,896), so the image is cut into 32x8 tiles dealt
+round-robin to the ranks, the scene is replicated, and the only exchange is ONE gather of the
+packed RGBA32F accumulators at the end of a batch.  torch.distributed is the
+plumbing: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class _DevArray:
+    """zero-copy view of a device pointer for torch.as_tensor (CUDA array interface v2)"""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def frame_tensor(renderer, device):
+    """The shard's packed accumulator (n_slots, 4) as a torch tensor aliasing the library's device memory."""
+    ptr, n = renderer.frame_device()
+    return torch.as_tensor(_DevArray(ptr, (n, 4)), device=device)
+
+
+def all_maps(W, H, world, shard_map_fn):
+    """(world * n_slots,) global pixel index of every packed slot of every rank, -1 = padding"""
+    return np.concatenate([shard_map_fn(W, H, r, world) for r in range(world)])
+
+
+def gather_frame(packed, W, H, world, maps, dst=0, group=None):
+    """ONE collective: gather every rank's packed accumulator (n_slots,4) on `dst`, then un-tile.
+
+    Returns the full (H, W, 4) image on rank `dst`, None elsewhere.  `maps` = all_maps(...) as a
+    torch int64 tensor on packed.device (built once)."""
+    rank = dist.get_rank(group) if world > 1 else 0
+    if world == 1:
+        gathered = packed
+    else:
+        if rank == dst:
+            gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+            dist.gather(packed, list(gathered.unbind(0)), dst=dst, group=group)
+            gathered = gathered.reshape(-1, 4)
+        else:
+            dist.gather(packed, None, dst=dst, group=group)
+            return None
+    valid = maps >= 0
+    full = torch.zeros((H * W, 4), dtype=packed.dtype, device=packed.device)
+    full[maps[valid]] = gathered[valid]
+    return full.reshape(H, W, 4)
