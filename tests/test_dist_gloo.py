@@ -1,0 +1,55 @@
+"""CPU, world_size 2 (gloo): the N > 1 host path — tile sharding, ONE gather of the packed accumulators, un-tiling.
+
+The per-rank render is stood in for by the oracle (allowed in tests only): each rank fills its packed,
+shard-local accumulator exactly the way the HIP renderer lays it out (pt_shard_map order), then runs
+the same shard.gather_frame() that bench.py runs over RCCL.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, W, H, out_path):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ptimport
+    pt = ptimport.load()
+    from pathtracer_0_amd import renderer, shard
+    import oracle
+    wl = pt.scenes.build("C2", W, H)
+    seeds = [pt.scenes.frame_seed(f) for f in (1, 2)]
+    full, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, 2, seeds, nthreads=1)
+    m = renderer.shard_map(W, H, rank, world)
+    packed = np.zeros((len(m), 4), np.float32)
+    packed[m >= 0] = full.reshape(-1, 4)[m[m >= 0]]            # what this rank's renderer would hold
+    maps = torch.from_numpy(shard.all_maps(W, H, world, renderer.shard_map).astype(np.int64))
+    got = shard.gather_frame(torch.from_numpy(packed), W, H, world, maps, dst=0)
+    if rank == 0:
+        np.save(out_path, np.stack([got.numpy(), full]))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H", [(96, 40), (100, 37)])
+def test_two_rank_gather_reassembles_the_frame(pt, tmp_path, W, H):
+    from pathtracer_0_amd import build
+    build.build_hip()
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker, args=(2, _free_port(), W, H, out), nprocs=2, join=True)
+    got, full = np.load(out)
+    assert np.array_equal(got, full)
