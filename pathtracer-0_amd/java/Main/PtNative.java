@@ -1,0 +1,33 @@
+package Main;
+
+import java.nio.Buffer;
+
+/**
+ * JNI face of libpt_hip.so (include/pt_api.h) for the reference's Java host.
+ *
+ * One method per C-ABI entry point the frame loop needs; direct NIO buffers are passed exactly
+ * where the reference hands them to glBufferData / glBufferSubData (dispatch.java:208-574, 628-643).
+ * Errors surface as RuntimeException, like the reference's check helpers (dispatch.java:1853-1865).
+ * NOT compiled in this repository's environment (no JDK); see INTEGRATION.md.
+ */
+public final class PtNative {
+    static { System.loadLibrary("pt_jni"); }     // pt_jni.c, linked against libpt_hip.so
+
+    private PtNative() {}
+
+    public static native long create(int device, int width, int height, int shardRank, int shardCount);
+    public static native void destroy(long ctx);
+    /** glBufferData(GL_SHADER_STORAGE_BUFFER, buf) + glBindBufferBase(binding): copy at call time */
+    public static native void setBuffer(long ctx, int binding, Buffer directBuffer, long bytes);
+    /** stbi_load + glTextureSubImage2D + bindless handle slot `index` (dispatch.java:334-378) */
+    public static native void setTexture(long ctx, int index, int width, int height, Buffer rgba8);
+    /** resetTexture(FRAME) (dispatch.java:732-735) */
+    public static native void resetFrame(long ctx);
+    /** glUniform1i(u_frameCount), glUniform1i(u_seed), glDrawArrays(GL_TRIANGLES,0,6) (dispatch.java:697-705) */
+    public static native void render(long ctx, int frameCount, int seed);
+    public static native void renderBatch(long ctx, int firstFrame, int[] seeds);
+    /** glFinish() */
+    public static native void synchronize(long ctx);
+    /** glReadPixels of the RGBA32F FRAME image into a direct FloatBuffer of width*height*4 floats */
+    public static native void readFrame(long ctx, Buffer rgbaOut);
+}

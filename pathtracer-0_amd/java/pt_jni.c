@@ -1,0 +1,49 @@
+/* pt_jni.c — the only file that includes jni.h: maps Main.PtNative onto the C ABI of include/pt_api.h.
+ *
+ * build (on a box with a JDK; none exists in this repository's environment):
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
+ *       -o libpt_jni.so pt_jni.c -L.. -lpt_hip -Wl,-rpath,'$ORIGIN/..'
+ *
+ * java.nio direct buffers -> GetDirectBufferAddress (zero copy on the Java side; the library copies at
+ * call time, glBufferData semantics); error codes -> RuntimeException with pt_last_error().
+ */
+#include <jni.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "pt_api.h"
+
+static void throw_rt(JNIEnv* env, const char* where) {
+    char msg[512];
+    snprintf(msg, sizeof msg, "%s: %s", where, pt_last_error());
+    (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), msg);
+}
+#define CHECK(call, where) do { if ((call) != PT_OK) { throw_rt(env, where); return; } } while (0)
+#define CTX(h) ((pt_ctx*)(intptr_t)(h))
+
+JNIEXPORT jlong JNICALL Java_Main_PtNative_create(JNIEnv* env, jclass c, jint device, jint w, jint h, jint rank, jint count) {
+    pt_ctx* ctx = NULL;
+    if (pt_create(&ctx, device, w, h, rank, count) != PT_OK) { throw_rt(env, "pt_create"); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_destroy(JNIEnv* env, jclass c, jlong h) { pt_destroy(CTX(h)); }
+JNIEXPORT void JNICALL Java_Main_PtNative_setBuffer(JNIEnv* env, jclass c, jlong h, jint binding, jobject buf, jlong bytes) {
+    void* p = (*env)->GetDirectBufferAddress(env, buf);
+    if (!p) { (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "setBuffer needs a direct NIO buffer"); return; }
+    CHECK(pt_set_buffer(CTX(h), binding, p, (size_t)bytes), "pt_set_buffer");
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_setTexture(JNIEnv* env, jclass c, jlong h, jint index, jint w, jint ht, jobject buf) {
+    CHECK(pt_set_texture(CTX(h), index, w, ht, (const uint8_t*)(*env)->GetDirectBufferAddress(env, buf)), "pt_set_texture");
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_resetFrame(JNIEnv* env, jclass c, jlong h) { CHECK(pt_reset_frame(CTX(h)), "pt_reset_frame"); }
+JNIEXPORT void JNICALL Java_Main_PtNative_render(JNIEnv* env, jclass c, jlong h, jint frameCount, jint seed) { CHECK(pt_render(CTX(h), frameCount, seed), "pt_render"); }
+JNIEXPORT void JNICALL Java_Main_PtNative_renderBatch(JNIEnv* env, jclass c, jlong h, jint first, jintArray seeds) {
+    jsize n = (*env)->GetArrayLength(env, seeds);
+    jint* s = (*env)->GetIntArrayElements(env, seeds, NULL);
+    int rc = pt_render_batch(CTX(h), first, (int)n, (const int32_t*)s);
+    (*env)->ReleaseIntArrayElements(env, seeds, s, JNI_ABORT);
+    if (rc != PT_OK) throw_rt(env, "pt_render_batch");
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_synchronize(JNIEnv* env, jclass c, jlong h) { CHECK(pt_synchronize(CTX(h)), "pt_synchronize"); }
+JNIEXPORT void JNICALL Java_Main_PtNative_readFrame(JNIEnv* env, jclass c, jlong h, jobject out) {
+    CHECK(pt_read_frame(CTX(h), (float*)(*env)->GetDirectBufferAddress(env, out)), "pt_read_frame");
+}
