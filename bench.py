@@ -42,6 +42,10 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--path-slots", type=int, default=None)
     ap.add_argument("--lds-budget", type=int, default=None)
+    ap.add_argument("--extend-mode", type=int, default=None)
+    ap.add_argument("--extend-tpb", type=int, default=None)
+    ap.add_argument("--extend-cache", type=int, default=None)
+    ap.add_argument("--refill-min", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
     args = ap.parse_args()
@@ -73,6 +77,9 @@ def main():
         r.set_option("path_slots", args.path_slots)
     if args.lds_budget is not None:
         r.set_option("lds_budget", args.lds_budget)
+    for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min)):
+        if val is not None:
+            r.set_option(name, val)
     stream = torch.cuda.Stream(dev)             # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)

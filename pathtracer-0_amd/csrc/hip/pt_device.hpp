@@ -109,6 +109,32 @@ PM_DEV vec3 vecmat(vec3 p, const float* M) {   // p * M, M row-major: component 
     return v3(dot(p, v3(M[0], M[3], M[6])), dot(p, v3(M[1], M[4], M[7])), dot(p, v3(M[2], M[5], M[8])));
 }
 
+
+// Record fetches.  The staged prefix lives in LDS, the rest in global memory; the two loads must stay two
+// instructions (ds_read_b128 / global_load_dwordx4).  Left alone, the compiler merges them into ONE flat_load
+// through a selected generic pointer, which sends even the LDS hits through the texture addresser — the empty
+// asm pins the LDS arm.
+PM_DEV void loadNode(const DevScene& sc, const float4* ldsN, int ref, float4& q0, float4& q1, float4& q2, float4& q3) {
+    if (ref < sc.ldsNodes) {
+        const float4* p = ldsN + 4 * ref;
+        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+        asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
+    } else {
+        const float4* p = sc.nodes + 4 * (size_t)ref;
+        q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+    }
+}
+PM_DEV void loadTri(const DevScene& sc, const float4* ldsT, int ti, float4& t0, float4& t1, float4& t2) {
+    if (ti < sc.ldsTris) {
+        const float4* p = ldsT + 3 * ti;
+        t0 = p[0]; t1 = p[1]; t2 = p[2];
+        asm volatile("" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x));
+    } else {
+        const float4* p = sc.tris + 3 * (size_t)ti;
+        t0 = p[0]; t1 = p[1]; t2 = p[2];
+    }
+}
+
 // rayScene's closest-hit search (frag.glsl:548-631) for one ray.  `stk`/`stride`: this lane's
 // traversal stack (LDS).  `ldsN`/`ldsT`: LDS copies of the first sc.ldsNodes / sc.ldsTris records.
 // Visit order, pruning tests and tie-breaks are the reference's (push far child first; prune
@@ -124,6 +150,7 @@ PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int s
         const ObjRoot R = sc.roots[ob];
         if (COUNT) cnt.boxtests++;
         if (rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]) > closest) continue;   // :468
+        if (R.ref == REF_EMPTY) { if (COUNT) cnt.nodes++; continue; }     // a root without triangles is visited and finds nothing
         int sp = 0;
         stk[0] = R.ref; sp = 1;
         while (sp > 0) {
@@ -131,8 +158,7 @@ PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int s
             if (COUNT) cnt.nodes++;
             if (ref >= 0) {
                 float4 q0, q1, q2, q3;
-                if (ref < sc.ldsNodes) { q0 = ldsN[4 * ref]; q1 = ldsN[4 * ref + 1]; q2 = ldsN[4 * ref + 2]; q3 = ldsN[4 * ref + 3]; }
-                else { const float4* p = sc.nodes + 4 * (size_t)ref; q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+                loadNode(sc, ldsN, ref, q0, q1, q2, q3);
                 if (COUNT) cnt.boxtests += 2;
                 float Ld = rayBox(o, invD, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
                 float Rd = rayBox(o, invD, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
@@ -152,8 +178,7 @@ PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int s
                 bool last;
                 do {
                     float4 t0, t1, t2;
-                    if (ti < sc.ldsTris) { t0 = ldsT[3 * ti]; t1 = ldsT[3 * ti + 1]; t2 = ldsT[3 * ti + 2]; }
-                    else { const float4* p = sc.tris + 3 * (size_t)ti; t0 = p[0]; t1 = p[1]; t2 = p[2]; }
+                    loadTri(sc, ldsT, ti, t0, t1, t2);
                     unsigned idl = __float_as_uint(t2.y);
                     last = (idl >> 31) != 0;
                     float t, u, v;

@@ -193,6 +193,164 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
     }
 }
 
+// Persistent, phase-selecting form of k_extend (the production intersect kernel).
+//  * grid sized to the machine; every block stages the top of the BVH (and, when they fit, the triangles) into LDS
+//    ONCE and then streams its share of the rays through it;
+//  * per wave: a lane whose ray is finished takes the next ray of the wave's static range (ballot + prefix
+//    popcount, no atomics) instead of idling until the slowest lane is done;
+//  * every trip through the loop the wave issues ONE instruction stream — the inner-node step or the leaf step —
+//    whichever more lanes are waiting for (ballot + popcount); the other lanes keep their entry for a later trip.
+//    The kernel is VALU-issue bound (profiles/): what counts is lanes busy per issued instruction;
+//  * the entry the reference would push last and pop next (the near child) stays in a register; only the far child
+//    goes through the LDS stack.
+// Per ray the sequence of visited nodes / tested triangles and every comparison are exactly rayBVH's (frag.glsl:
+// 452-537): a lane never steps past a pending leaf, so `closest` evolves in the reference's order.
+constexpr int CUR_NONE = 0x7fffffff;
+
+template <bool COUNT, typename StackT, int TPB>
+__global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* queue, const unsigned* nQueue, int nSlots,
+                                                       Control* ctl, int refillMin, int stackDepth, int nObjLds) {
+    extern __shared__ float4 smem[];
+    float4* ldsN = smem;
+    float4* ldsT = smem + 4 * sc.ldsNodes;
+    // per-lane root-box distances (rayNode(o,d,root) of :468 depends on the ray only, so it is evaluated once per ray
+    // when the lane takes the ray — all refilled lanes together — and only compared against `closest` later)
+    float* rootDist = reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + threadIdx.x;
+    StackT* stk = reinterpret_cast<StackT*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB) + threadIdx.x;
+    (void)stackDepth;
+    for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += TPB) ldsN[k] = sc.nodes[k];
+    for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += TPB) ldsT[k] = sc.tris[k];
+    __syncthreads();
+    const unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    const unsigned nWaves = gridDim.x * (TPB / 64), waveId = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const unsigned per = (((n + nWaves - 1) / nWaves) + 63u) & ~63u;       // static range of this wave, 64-aligned -> coalesced first fill
+    unsigned pos = waveId * per;
+    const unsigned end = min(pos + per, n);
+    bool active = false;
+    vec3 o = v3(0.0f), d = v3(0.0f), invD = v3(0.0f);
+    float closest = 1e30f, hu = 0.0f, hv = 0.0f;
+    int prim = PRIM_NONE, ob = 0, sp = 0, cur = CUR_NONE;
+    unsigned slot = 0;
+    Counters c;
+    for (;;) {
+        // ---- refill idle lanes from the wave's range
+        unsigned long long idle = __ballot(!active);
+        int nIdle = __popcll(idle);
+        if (pos < end && nIdle >= refillMin) {                              // wave-uniform
+            if (!active) {
+                unsigned q = pos + (unsigned)__popcll(idle & ltMask);
+                if (q < end) {
+                    slot = queue ? queue[q] : q;
+                    float4 g0 = st.G0[slot], g1 = st.G1[slot];
+                    if (__float_as_uint(g1.w) & FL_ALIVE) {
+                        d = v3(g0.w, g1.x, g1.y);
+                        o = madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));          // o = o + 1e-4*d  (:549)
+                        invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; ob = 0; sp = 0; cur = CUR_NONE;
+                        active = true;
+                        for (int k = 0; k < nObjLds; k++) {
+                            const ObjRoot R = sc.roots[k];
+                            rootDist[k * TPB] = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+                        }
+                    }
+                }
+            }
+            pos += (unsigned)nIdle;
+            nIdle = __popcll(__ballot(!active));
+        }
+        if (nIdle == 64) { if (pos >= end) break; continue; }
+        const bool wNext = active && cur == CUR_NONE;
+        // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire
+        if (__any(wNext)) {
+            if (wNext) {
+                while (ob < sc.numObj) {
+                    float rd;
+                    if (ob < nObjLds) rd = rootDist[ob * TPB];
+                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); }
+                    const int rref = sc.roots[ob].ref;
+                    ob++;
+                    if (COUNT) c.boxtests++;
+                    if (rd > closest) continue;
+                    if (rref == REF_EMPTY) { if (COUNT) c.nodes++; continue; }
+                    cur = rref;
+                    break;
+                }
+                if (cur == CUR_NONE) {                                      // all BVHs done: ellipsoids (:606-631), then retire the ray
+                    for (int i = 0; i < sc.numEllip; i++) {
+                        const EllipRec& E = sc.ellip[i];
+                        vec3 cc = v3(E.c[0], E.c[1], E.c[2]);
+                        float t;
+                        if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        if (t < closest) { closest = t; prim = PRIM_ELLIPSOID | i; }
+                    }
+                    st.H[slot] = make_float4(closest, hu, hv, __int_as_float(prim));
+                    active = false;
+                }
+            }
+        }
+        const bool wInner = active && cur >= 0 && cur != CUR_NONE, wLeaf = active && cur < 0;
+        const int nInner = __popcll(__ballot(wInner)), nLeaf = __popcll(__ballot(wLeaf));
+        if (nInner >= nLeaf && nInner > 0) {
+            // ---- inner-node step (:521-532)
+            if (wInner) {
+                float4 q0, q1, q2, q3;
+                loadNode(sc, ldsN, cur, q0, q1, q2, q3);
+                if (COUNT) { c.nodes++; c.boxtests += 2; }
+                float Ld = rayBox(o, invD, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+                float Rd = rayBox(o, invD, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
+                bool pl = Ld < closest, pr = Rd < closest;
+                if (COUNT) { if (pl && lref == REF_EMPTY) c.nodes++; if (pr && rref == REF_EMPTY) c.nodes++; }
+                pl = pl && lref != REF_EMPTY; pr = pr && rref != REF_EMPTY;
+                // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
+                bool rNear = Ld > Rd;
+                int nearRef = rNear ? rref : lref, farRef = rNear ? lref : rref;
+                bool nearOk = rNear ? pr : pl, farOk = rNear ? pl : pr;
+                if (nearOk) {
+                    cur = nearRef;
+                    if (farOk) { stk[sp * TPB] = (StackT)farRef; sp++; }
+                } else if (farOk) {
+                    cur = farRef;
+                } else if (sp > 0) {
+                    cur = (int)stk[(--sp) * TPB];
+                } else {
+                    cur = CUR_NONE;
+                }
+            }
+        } else if (nLeaf > 0) {
+            // ---- leaf step: one triangle of the pending leaf (:483-520)
+            if (wLeaf) {
+                int ti = -(cur + 1);
+                float4 t0, t1, t2;
+                loadTri(sc, ldsT, ti, t0, t1, t2);
+                unsigned idl = __float_as_uint(t2.y);
+                float t, u, v;
+                if (COUNT) c.tritests++;
+                rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
+                if (t > 0.0f && t < closest) {                              // :489
+                    closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
+                    if (COUNT) c.hitupd++;
+                }
+                if (idl >> 31) {                                            // last triangle of the leaf: this node is done
+                    if (COUNT) c.nodes++;
+                    cur = (sp > 0) ? (int)stk[(--sp) * TPB] : CUR_NONE;
+                } else {
+                    cur = cur - 1;                                          // next triangle record of the same leaf
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
+        atomicAdd(&ctl->cnt[PT_CNT_TRITESTS], (unsigned long long)c.tritests);
+        atomicAdd(&ctl->cnt[PT_CNT_HITUPD], (unsigned long long)c.hitupd);
+        atomicAdd(&ctl->cnt[PT_CNT_BOXTESTS], (unsigned long long)c.boxtests);
+    }
+}
+
 // trace() loop body + sample/job bookkeeping for every live path slot
 template <bool TRANS, bool STATS>
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
@@ -360,7 +518,7 @@ struct pt_ctx {
     std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; int* dAllMaps = nullptr;
     float4* dFrame = nullptr;
     // path pool
-    int poolSlots = 1 << 20; int allocSlots = 0; bool allocTrans = false;
+    int poolSlots = 1 << 22; int allocSlots = 0; bool allocTrans = false;
     State st{};
     unsigned *dQueueA = nullptr, *dQueueB = nullptr, *dNQueue = nullptr;
     float4* dColbuf = nullptr; size_t colbufElems = 0;
@@ -371,6 +529,9 @@ struct pt_ctx {
     // options / stats
     bool countStats = false, timing = false;
     int ldsBudget = 20 * 1024;
+    int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
+    int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
+    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0;
     int compactBelowPct = 70;       // compact the queue when fewer than this % of the launched lanes are live
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; } kt[4];
@@ -548,6 +709,14 @@ int buildScene(pt_ctx* c) {
         if (ln < sc.nNodes) lt = std::min(lt, 0);               // triangles only once every node fits
     }
     sc.ldsNodes = ln; sc.ldsTris = lt;
+    // persistent kernel: one staged tile per resident block
+    c->stack16 = sc.nNodes < 32767 && sc.nTriRecs < 32767;
+    {
+        int cb = c->extendCacheBytes;
+        int pn = std::min(sc.nNodes, cb / 64);
+        int pt_ = (pn == sc.nNodes) ? std::min(sc.nTriRecs, (cb - pn * 64) / 48) : 0;
+        c->pLdsNodes = pn; c->pLdsTris = pt_;
+    }
     c->sceneDirty = false;
     return 0;
 }
@@ -585,6 +754,35 @@ int nextEventPair(pt_ctx::KT& k) {
         __VA_ARGS__;                                                     \
         if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].second, s);     \
     } while (0)
+
+template <bool COUNT, typename StackT, int TPB>
+void launchEP(pt_ctx* c, const DevScene& sc, size_t lds, int grid, const unsigned* queue, int launched) {
+    int nObjLds = std::min(sc.numObj, 8);
+    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, c->stream, sc, c->st, queue, c->dNQueue, launched, c->dCtl, c->refillMin,
+                       c->stackDepth, nObjLds);
+}
+void launchExtendPersist(pt_ctx* c, const unsigned* queue, int launched) {
+    DevScene sc = c->sc;
+    int tpb = c->extendTpb;
+    // LDS per block: [node tile][triangle tile][root-box distances][traversal stacks]; the tile takes what the fixed parts leave
+    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stack16 ? 2 : 4) + 64;
+    size_t avail = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
+    size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, avail);
+    sc.ldsNodes = (int)std::min<size_t>((size_t)sc.nNodes, cb / 64);
+    sc.ldsTris = (sc.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)sc.ldsNodes * 64) / 48) : 0;
+    size_t lds = (size_t)sc.ldsNodes * 64 + (size_t)sc.ldsTris * 48 + fixed;
+    lds = (lds + 15) & ~(size_t)15;
+    int perCU = std::max(1, std::min((int)(160 * 1024 / std::max<size_t>(lds, 1)), 2048 / tpb));
+    int grid = c->numCUs * perCU;
+    int maxUseful = (launched + tpb - 1) / tpb;                  // never more blocks than 1 lane per ray
+    grid = std::max(1, std::min(grid, maxUseful));
+#define EP(COUNT, T, TPB) launchEP<COUNT, T, TPB>(c, sc, lds, grid, queue, launched)
+#define EP_T(COUNT, T) do { if (tpb == 256) EP(COUNT, T, 256); else if (tpb == 512) EP(COUNT, T, 512); else EP(COUNT, T, 1024); } while (0)
+    if (c->countStats) { if (c->stack16) EP_T(true, short); else EP_T(true, int); }
+    else { if (c->stack16) EP_T(false, short); else EP_T(false, int); }
+#undef EP
+#undef EP_T
+}
 
 int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     if (nFrames < 1) return fail(PT_ERR_ARG, "n_frames must be >= 1");
@@ -634,8 +832,12 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     while (alive > 0) {
         for (int k = 0; k < CHECK; k++) {
             int grid = (int)((launched + BLOCK - 1) / BLOCK);
-            if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
-            else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+            if (c->extendMode == 0) {
+                if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+                else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
+            } else {
+                TIMED_LAUNCH(0, launchExtendPersist(c, queue, (int)launched));
+            }
 #define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl
             if (c->trans) { if (c->countStats) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<true, true>), SHADE_ARGS)); else TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<true, false>), SHADE_ARGS)); }
             else { if (c->countStats) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<false, true>), SHADE_ARGS)); else TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<false, false>), SHADE_ARGS)); }
@@ -692,6 +894,7 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     pt_ctx* c = new pt_ctx();
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->device = device; c->W = width; c->H = height; c->shardRank = shard_rank; c->shardCount = shard_count;
     HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
@@ -844,6 +1047,10 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 1: c->countStats = value != 0; return PT_OK;
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
         case 3: c->compactBelowPct = (int)value; return PT_OK;
+        case 4: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "extend mode must be 0 or 1"); c->extendMode = (int)value; return PT_OK;
+        case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
+        case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
+        case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");
 }

@@ -96,10 +96,19 @@ def test_intersect_parity(pt, oracle, renderer_mod, name, W, H):
             assert prim[i] == exp and tuv[i, 0] == out[0], (i, prim[i], exp, tuv[i, 0], out[0])
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("name,W,H,frames", [("C1", 64, 64, 2), ("C2", 96, 54, 3), ("C3", 96, 54, 3), ("C5", 64, 36, 2)])
-def test_render_parity_small(pt, oracle, renderer_mod, name, W, H, frames):
+def test_render_parity_small(pt, oracle, renderer_mod, name, W, H, frames, mode):
     wl = pt.scenes.build(name, W, H) if name != "C5" else pt.scenes.build(name, W, H, subdiv=2)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, frames)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, frames, extend_mode=mode)
+    assert_same(got, ref, cnt, ocnt)
+
+
+@pytest.mark.parametrize("tpb,cache,refill", [(256, 0, 1), (512, 8192, 16), (1024, 65536, 48), (512, 150000, 64)])
+def test_render_parity_persistent_variants(pt, oracle, renderer_mod, tpb, cache, refill):
+    """persistent intersect kernel: block size, LDS tile size (partial / whole BVH) and refill threshold do not change results"""
+    wl = pt.scenes.build("C3", 128, 72)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, extend_mode=1, extend_tpb=tpb, extend_cache_bytes=cache, refill_min=refill)
     assert_same(got, ref, cnt, ocnt)
 
 
