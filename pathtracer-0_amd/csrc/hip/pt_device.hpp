@@ -55,7 +55,7 @@ struct DevScene {
     const ObjRoot* roots; int numObj;
     const EllipRec* ellip; int numEllip;
     const MatRec* mats;   int numMat;
-    const uchar4* sky;    int skyW, skyH;
+    const float4* sky;    int skyW, skyH;   // texture 0 as RGBA32F: texel = byte / 255.0f (the same binary32 division, done once at upload)
     int ldsNodes, ldsTris;                   // how many leading node / triangle records the intersect kernel stages in LDS
 };
 
@@ -277,11 +277,11 @@ PM_DEV vec3 sampleSky(const DevScene& sc, float u, float v) {
     int i0 = imod((int)flu, w), j0 = imod((int)flv, h);
     int i1 = imod(i0 + 1, w), j1 = imod(j0 + 1, h);
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-    uchar4 p00 = sc.sky[j0 * w + i0], p10 = sc.sky[j0 * w + i1], p01 = sc.sky[j1 * w + i0], p11 = sc.sky[j1 * w + i1];
+    float4 p00 = sc.sky[j0 * w + i0], p10 = sc.sky[j0 * w + i1], p01 = sc.sky[j1 * w + i0], p11 = sc.sky[j1 * w + i1];
     vec3 r;
-    r.x = w00 * ((float)p00.x / 255.0f) + w10 * ((float)p10.x / 255.0f) + w01 * ((float)p01.x / 255.0f) + w11 * ((float)p11.x / 255.0f);
-    r.y = w00 * ((float)p00.y / 255.0f) + w10 * ((float)p10.y / 255.0f) + w01 * ((float)p01.y / 255.0f) + w11 * ((float)p11.y / 255.0f);
-    r.z = w00 * ((float)p00.z / 255.0f) + w10 * ((float)p10.z / 255.0f) + w01 * ((float)p01.z / 255.0f) + w11 * ((float)p11.z / 255.0f);
+    r.x = w00 * p00.x + w10 * p10.x + w01 * p01.x + w11 * p11.x;
+    r.y = w00 * p00.y + w10 * p10.y + w01 * p01.y + w11 * p11.y;
+    r.z = w00 * p00.z + w10 * p10.z + w01 * p01.z + w11 * p11.z;
     return r;
 }
 PM_DEV vec3 bgCol(const DevScene& sc, vec3 In) {
@@ -304,13 +304,16 @@ PM_DEV float fresnelReflectAmount(float n1, float n2, vec3 normal, vec3 incidenc
     return r0 + (1.0f - r0) * x * x * x * x * x;
 }
 
-// chooseRay, frag.glsl:745-809
-PM_DEV vec3 chooseRay(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint32_t& rng, int& winType) {
+// chooseRay, frag.glsl:745-809, split at its random-vector draw so that the kernel has ONE call site of
+// randLambertianDistVec for all lobes (each inlined copy is a separate divergent instruction stream; the
+// shading kernel is VALU-issue bound).  chooseLobe = weights + roll (+ the subsurface draw) -> winType;
+// lobeDirection = the out direction for that winType from the already drawn Gaussian vector G.
+// RNG draw order is the reference's: roll, [subsurface draw], 6 Gaussian draws (none for transmission).
+PM_DEV int chooseLobe(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint32_t& rng) {
     float reflectionWeight = 1.0f - m.Pr;
     float clearcoatWeight = m.Pc;
     float transmissionWeight = (m.Tr > 0.0f ? m.Tr : (m.Tf[0] > 0.0f ? (m.Tf[0] + m.Tf[1] + m.Tf[2]) / 3.0f : 0.0f));
     float subsurfaceWeight = m.subsurface;
-    float eta = n1 / n2;
     float fresnel = 0.0f;
     if (m.illum == 5 || m.illum == 7 || transmissionWeight > 0.0f) {
         fresnel = fresnelReflectAmount(n1, n2, N, D);
@@ -321,22 +324,17 @@ PM_DEV vec3 chooseRay(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint3
     float totalWeight = diffuseWeight + reflectionWeight + clearcoatWeight + transmissionWeight;
     reflectionWeight /= totalWeight; clearcoatWeight /= totalWeight; transmissionWeight /= totalWeight;
     float roll = random_(rng);
-    vec3 outDir;
-    if (roll < reflectionWeight) {
-        winType = 1;
-        outDir = mix(reflect(D, N), normalize(randLambertianDistVec(rng) + N), 0.0f);     // Q-8
-    } else if (roll < reflectionWeight + clearcoatWeight) {
-        winType = 2;
-        outDir = mix(reflect(D, N), normalize(randLambertianDistVec(rng) + N), m.Pcr);
-    } else if (roll < reflectionWeight + clearcoatWeight + transmissionWeight) {
-        winType = 3;
-        outDir = refract(D, N, eta);
-    } else {
-        winType = 0;
-        if (subsurfaceWeight > 0.0f) { if (random_(rng) < subsurfaceWeight) winType = 4; }
-        outDir = normalize(randLambertianDistVec(rng) + N);
-    }
-    return outDir;
+    if (roll < reflectionWeight) return 1;
+    if (roll < reflectionWeight + clearcoatWeight) return 2;
+    if (roll < reflectionWeight + clearcoatWeight + transmissionWeight) return 3;
+    if (subsurfaceWeight > 0.0f) { if (random_(rng) < subsurfaceWeight) return 4; }
+    return 0;
+}
+PM_DEV vec3 lobeDirection(int w, vec3 G, vec3 N, vec3 D, float eta, float Pcr) {
+    if (w == 3) return refract(D, N, eta);                                        // :783
+    vec3 rough = normalize(G + N);
+    if (w == 1 || w == 2) return mix(reflect(D, N), rough, w == 1 ? 0.0f : Pcr);  // :775 (Q-8), :779
+    return rough;                                                                 // :795-804
 }
 
 // Sample set-up of main(), frag.glsl:885-910, for global pixel (px,py): new camera ray + trace() prologue (:811-818).
@@ -373,39 +371,47 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
 template <bool TRANS>
 PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim) {
     p.bounce++;                                               // :821
-    if (prim == PRIM_NONE || !(ht < 1e25f)) {                 // hit.id > -1 (:823) / closest_t < 1e25 (:634)
-        p.inc = p.inc + bgCol(sc, p.D) * p.col;              // :877
+    const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
+    const vec3 D = p.D;
+    vec3 N = v3(0.0f), Ke = v3(0.0f), albedoKd = v3(0.0f), albedoKs = v3(0.0f), Tf = v3(0.0f);
+    float ND = 0.0f, n1 = 1.0f, n2 = 1.0f, Pcr = 0.0f, Density = 0.0f;
+    int w = 0;
+    if (hit) {
+        vec3 o = madd(D, 1e-4f, p.O);
+        vec3 loc = madd(D, ht, o);                            // result.loc = o + closest_t*d (:635)
+        int mat;
+        if (prim & PRIM_ELLIPSOID) {
+            const EllipRec& E = sc.ellip[prim & 0xffffff];
+            vec3 c = v3(E.c[0], E.c[1], E.c[2]);
+            if (E.rotated) N = normalize(vecmat(loc - c, E.RB)); else N = normalize(loc - c);     // :622-626
+            mat = E.mat;
+        } else {
+            const float4* S = sc.shade + 4 * (size_t)prim;
+            float4 s0 = S[0], s1 = S[1], s2 = S[2];
+            vec3 vn1 = v3(s0.x, s0.y, s0.z), vn2 = v3(s0.w, s1.x, s1.y);
+            if (vn1.x != 0.0f && vn1.y != 0.0f && vn1.z != 0.0f) N = normalize(vn2 * hu + vn2 * hv + vn1 * (1.0f - hu - hv));   // :501-504 (Q-3)
+            else N = vn2;                                                                                              // :506 (Q-4)
+            mat = __float_as_int(s2.w);
+        }
+        const MatRec m = sc.mats[mat];
+        p.O = loc;                                            // :824
+        ND = dot(N, D);
+        N = N * (ND > 0.0f ? -1.0f : 1.0f);                   // :830
+        if (TRANS) {
+            if (ND < 0.0f) { addToIndiceStack(p, m.Ni); n1 = p.s[1]; n2 = p.s[0]; }           // :833-836
+            else { n1 = p.s[0]; n2 = p.s[1]; removeFirstOfIndiceStack(p); }                    // :838-840
+        }
+        w = chooseLobe(m, n1, n2, N, D, p.rng);               // :843 up to the lobe decision
+        Ke = v3(m.Ke[0], m.Ke[1], m.Ke[2]); albedoKd = v3(m.Kd[0], m.Kd[1], m.Kd[2]); albedoKs = v3(m.Ks[0], m.Ks[1], m.Ks[2]);
+        Tf = v3(m.Tf[0], m.Tf[1], m.Tf[2]); Pcr = m.Pcr; Density = m.Density;
+    }
+    vec3 G = v3(0.0f);
+    if (hit && w != 3) G = randLambertianDistVec(p.rng);      // the single random-vector site of the shading stage
+    if (!hit) {
+        p.inc = p.inc + bgCol(sc, D) * p.col;                 // :877
         return true;
     }
-    vec3 D = p.D;
-    vec3 o = madd(D, 1e-4f, p.O);
-    vec3 loc = madd(D, ht, o);                                // result.loc = o + closest_t*d (:635)
-    vec3 N; int mat;
-    if (prim & PRIM_ELLIPSOID) {
-        const EllipRec& E = sc.ellip[prim & 0xffffff];
-        vec3 c = v3(E.c[0], E.c[1], E.c[2]);
-        if (E.rotated) N = normalize(vecmat(loc - c, E.RB)); else N = normalize(loc - c);     // :622-626
-        mat = E.mat;
-    } else {
-        const float4* S = sc.shade + 4 * (size_t)prim;
-        float4 s0 = S[0], s1 = S[1], s2 = S[2];
-        vec3 n1 = v3(s0.x, s0.y, s0.z), n2 = v3(s0.w, s1.x, s1.y);
-        if (n1.x != 0.0f && n1.y != 0.0f && n1.z != 0.0f) N = normalize(n2 * hu + n2 * hv + n1 * (1.0f - hu - hv));   // :501-504 (Q-3)
-        else N = n2;                                                                                             // :506 (Q-4)
-        mat = __float_as_int(s2.w);
-    }
-    const MatRec m = sc.mats[mat];
-    p.O = loc;                                                // :824
-    float ND = dot(N, D);
-    N = N * (ND > 0.0f ? -1.0f : 1.0f);                       // :830
-    float n1 = 1.0f, n2 = 1.0f;
-    if (TRANS) {
-        if (ND < 0.0f) { addToIndiceStack(p, m.Ni); n1 = p.s[1]; n2 = p.s[0]; }           // :833-836
-        else { n1 = p.s[0]; n2 = p.s[1]; removeFirstOfIndiceStack(p); }                    // :838-840
-    }
-    int w = 0;
-    vec3 newD = chooseRay(m, n1, n2, N, D, p.rng, w);         // :843
-    p.D = newD;
+    p.D = lobeDirection(w, G, N, D, n1 / n2, Pcr);
     if (TRANS && w == 3) {                                    // :847-863
         if (ND < 0.0f) {
             if (p.inObj) { p.dist = distance(p.enter, p.O); p.applyAbs = true; }
@@ -417,16 +423,14 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
             p.applyAbs = true;
         }
     }
-    vec3 Ke = v3(m.Ke[0], m.Ke[1], m.Ke[2]);
     p.inc = p.inc + Ke * p.col;                               // :865
     if (length(p.col) < 0.1f) return true;                    // :866
     if (TRANS && p.applyAbs) {
-        vec3 Tf = v3(m.Tf[0], m.Tf[1], m.Tf[2]);
-        p.col = p.col * exp3((-Tf) * p.dist * m.Density);    // :868
+        p.col = p.col * exp3((-Tf) * p.dist * Density);      // :868
         p.applyAbs = false;
     } else if (w == 4) {
     } else {
-        p.col = p.col * (w == 2 ? v3(m.Ks[0], m.Ks[1], m.Ks[2]) : v3(m.Kd[0], m.Kd[1], m.Kd[2]));   // :873
+        p.col = p.col * (w == 2 ? albedoKs : albedoKd);      // :873
     }
     return !((float)p.bounce < fc.MAX_BOUNCES);               // loop condition :820
 }

@@ -128,6 +128,7 @@ __device__ __forceinline__ void storePath(const State& st, unsigned i, const Pat
 }
 
 // A new pixel-frame job (one fragment-shader invocation): fresh "globals" (SURVEY.md Q-1), rngState = index + u_seed.
+// The caller follows up with startSample (kept separate so that k_shade has a single startSample site).
 __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, unsigned job, Path& p) {
     unsigned fi = job / (unsigned)b.nLocal, k = job - fi * (unsigned)b.nLocal;
     int gp = b.pixList[k];
@@ -144,7 +145,6 @@ __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, u
     for (int i = 0; i < 10; i++) p.s[i] = 0.0f;
     p.stackSize = 0;
     p.alive = true;
-    startSample(fc, b.W, b.H, px, py, p);
 }
 
 template <bool TRANS>
@@ -155,6 +155,8 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Batch b, const FrameConst* f
     Path p;
     if (i < b.nJobs) {
         startJob(b, fc, i, p);
+        int gp = b.pixList[i % (unsigned)b.nLocal];
+        startSample(fc, b.W, b.H, gp % b.W, gp / b.W, p);
     } else {
         p = Path();
         p.alive = false; p.job = 0; p.rng = 0; p.bounce = 0; p.sample = 0; p.stackSize = 0; p.inObj = false; p.applyAbs = false;
@@ -364,7 +366,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
     float4 g1 = valid ? st.G1[i] : make_float4(0, 0, 0, 0);
     unpackFlags(p, __float_as_uint(g1.w));
     bool live = valid && p.alive;
-    bool jobDone = false;
+    bool jobDone = false, needStart = false;
     unsigned nSamp = 0;
     if (live) {
         float4 g0 = st.G0[i], g2 = st.G2[i], g3 = st.G3[i], g4 = st.G4[i], h = st.H[i];
@@ -386,9 +388,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
             p.sample++;
             nSamp = 1;
             if ((float)p.sample < fc.SAMPLE_RES) {                 // loop condition :898
-                unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
-                int gp = b.pixList[k];
-                startSample(fc, b.W, b.H, gp % b.W, gp / b.W, p);
+                needStart = true;
             } else {
                 unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
                 unsigned ls = (b.shardCount == 1) ? (unsigned)b.pixList[k] : k;
@@ -418,8 +418,13 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; w++) off += (w < wave) ? sCnt[w] : 0u;
         unsigned job = sBase + off + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-        if (job < b.nJobs) startJob(b, fc, job, p);
+        if (job < b.nJobs) { startJob(b, fc, job, p); needStart = true; }
         else p.alive = false;
+    }
+    if (needStart) {                                              // the single camera-ray site: next sample of the job, or first of a new one
+        unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
+        int gp = b.pixList[k];
+        startSample(fc, b.W, b.H, gp % b.W, gp / b.W, p);
     }
     unsigned long long dead = __ballot(jobDone && !p.alive);
     if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
@@ -512,7 +517,7 @@ struct pt_ctx {
     int stackDepth = 1;
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
-    uchar4* dSky = nullptr;
+    float4* dSky = nullptr;
     DevScene sc{};
     // shard
     std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; int* dAllMaps = nullptr;
@@ -693,7 +698,10 @@ int buildScene(pt_ctx* c) {
     if ((rc = uploadVec((void**)&c->dRoots, roots.data(), roots.size() * sizeof(ObjRoot), s))) return rc;
     if ((rc = uploadVec((void**)&c->dEllip, er.data(), er.size() * sizeof(EllipRec), s))) return rc;
     if ((rc = uploadVec((void**)&c->dMats, mats.data(), mats.size() * sizeof(MatRec), s))) return rc;
-    if ((rc = uploadVec((void**)&c->dSky, c->sky.data(), c->sky.size(), s))) return rc;
+    std::vector<float4> skyf((size_t)c->skyW * c->skyH);
+    for (size_t k = 0; k < skyf.size(); k++)
+        skyf[k] = f4((float)c->sky[4 * k] / 255.0f, (float)c->sky[4 * k + 1] / 255.0f, (float)c->sky[4 * k + 2] / 255.0f, (float)c->sky[4 * k + 3] / 255.0f);
+    if ((rc = uploadVec((void**)&c->dSky, skyf.data(), skyf.size() * 16, s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     DevScene& sc = c->sc;
     sc.nodes = c->dNodes; sc.nNodes = (int)order.size(); sc.tris = c->dTris; sc.nTriRecs = (int)(triRecs.size() / 3);

@@ -171,3 +171,65 @@ def test_errors_surface(pt, renderer_mod):
         r.render(1, 1)
     assert e.value.code == -4
     r.close()
+
+
+def test_render_parity_c4_big_bvh(pt, oracle, renderer_mod):
+    """C4: one 100k-triangle BVH (int32 stack entries, deep tree, nodes mostly outside the LDS tile)"""
+    wl = pt.scenes.build("C4", 96, 54)
+    assert wl.info["triangles"] > 100000
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
+    assert_same(got, ref, cnt, ocnt)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 1, extend_mode=0)
+    assert_same(got, ref, cnt, ocnt)
+
+
+def test_render_parity_c5_16_bounces(pt, oracle, renderer_mod):
+    """C5 materials (clearcoat, subsurface, the reference's "test" material with Tr) at 16 bounces"""
+    wl = pt.scenes.build("C5", 96, 54)
+    assert wl.max_bounces == 16
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
+    assert_same(got, ref, cnt, ocnt)
+
+
+def test_sky_texture_bilinear_repeat(pt, oracle, renderer_mod):
+    """K3 on the device: a non-trivial RGBA8 sky through the software LINEAR/REPEAT sampler"""
+    wl = pt.scenes.build("C1", 64, 64)
+    rs = np.random.RandomState(5)
+    wl.sky = rs.randint(0, 256, size=(5, 7, 4)).astype(np.uint8)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
+    assert_same(got, ref, cnt, ocnt)
+
+
+def test_rotated_camera_and_rotated_ellipsoid(pt, oracle, renderer_mod):
+    """rotate()/rotateBack() paths (frag.glsl:244-297, Q-15) and a camera with all three angles set"""
+    wl = pt.scenes.build("C1", 64, 48)
+    b = dict(wl.buffers)
+    b[1] = np.array([0.2, -0.3, 0.1], np.float32)
+    e = b[7].copy(); n = int(e[0]); e[1 + 6 * n: 1 + 6 * n + 3] = [0.3, 0.2, 0.1]     # rotate the first ellipsoid
+    b[7] = e
+    wl2 = pt.scenes.Workload(wl.name, wl.W, wl.H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl2, 2)
+    assert_same(got, ref, cnt, ocnt)
+
+
+def test_full_size_properties_c3(pt, oracle, renderer_mod):
+    """BASELINE.json's full C3 size (1920x1080, 8 spp/frame): size-independent properties + oracle parity on a pixel lattice"""
+    W, H = 1920, 1080
+    wl = pt.scenes.build("C3", W, H)
+    seeds = seeds_for(pt, 1, 4)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch(1, seeds)
+    a = r.read_frame().copy()
+    r.reset_frame()
+    r.render_batch(1, seeds[:1]); r.render_batch(2, seeds[1:3]); r.render(4, seeds[3])     # any split of the batch: same bits
+    b = r.read_frame().copy()
+    r.close()
+    assert np.array_equal(a, b)
+    assert np.all(a[..., 3] == 4.0) and np.isfinite(a[..., :3]).all() and (a[..., :3] >= 0).all()
+    # the oracle on every 24th pixel in x and 27th in y, same frames
+    sc = oracle.Scene.from_workload(wl)
+    ref = np.zeros((H, W, 4), np.float32)
+    for i, s in enumerate(seeds):
+        oracle.render(sc, W, H, 1 + i, s, ref, nthreads=8, xs=24, ys=27)
+    assert np.array_equal(a[::27, ::24], ref[::27, ::24])
