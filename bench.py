@@ -90,11 +90,16 @@ def main():
 
     frame_no = [1]
 
+    MAX_BATCH = 32      # frames per wavefront batch (bounds the per-frame staging buffer: 16 B x pixels x frames)
+
     def step():
-        first = frame_no[0]
-        seeds = [scenes.frame_seed(f) for f in range(first, first + fps)]
-        r.render_batch(first, seeds)
-        frame_no[0] += fps
+        done = 0
+        while done < fps:
+            n = min(MAX_BATCH, fps - done)
+            first = frame_no[0]
+            r.render_batch(first, [scenes.frame_seed(f) for f in range(first, first + n)])
+            frame_no[0] += n
+            done += n
         return shard.gather_frame(packed, W, H, world, maps, dst=0)
 
     def fence():
@@ -156,8 +161,16 @@ def main():
         avg_ms = ms_ext / max(n_ext, 1)
         bytes_per_launch = bytes_per_seg_extend * seg / max(n_ext, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "kernel": "k_extend", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        traffic, traffic_src = None, None
+        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")        # PMC-measured HBM bytes per segment (scripts/profile.sh -> summarize_prof.py)
+        if os.path.exists(tf):
+            tj = json.load(open(tf))
+            k = tj["kernels"].get("k_extend_persist") or tj["kernels"].get("k_extend")
+            if k:
+                traffic = round(k["hbm_bytes_per_segment"] * seg / max(n_ext, 1))
+                traffic_src = "profiles/hbm_traffic.json"
+        out["roofline"] = {"bound": "hbm", "kernel": "k_extend_persist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "avg_launch_ms": round(avg_ms, 4), "launches": n_ext, "algorithmic_bytes_per_launch": round(bytes_per_launch),
                            "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3), "bytes": round(bytes_per_seg_extend, 1)},
                            "segments_per_sample": round(S, 3), "bytes_per_sample_whole_path": round(bytes_per_sample, 1),
@@ -171,7 +184,7 @@ def main():
         import oracle
         cores = min(os.cpu_count() or 1, 16)
         sc = oracle.Scene.from_workload(wl)
-        xs = ys = 2 if W * H > 500000 else 1
+        xs = ys = 2 if W * H > 3000000 else 1
         buf = np.zeros((H, W, 4), dtype=np.float32)
         tc = time.perf_counter()
         _, ocnt = oracle.render(sc, W, H, 1, scenes.frame_seed(1), buf, nthreads=cores, xs=xs, ys=ys)

@@ -17,8 +17,9 @@ using namespace pm;
 //
 //  inner node  = 4 x float4 (64 B): both children's boxes + both child references, so one record
 //                per node visit replaces BVHtree[3n+1..2] + 2 x BVHdata rows of the reference:
-//                  q0 = lmin.xyz, lmax.x   q1 = lmax.yz, rmin.xy   q2 = rmin.z, rmax.xyz
-//                  q3 = (lref, rref, 0, 0) as int bits
+//                  q0 = (lmin.x, rmin.x, lmin.y, rmin.y)  q1 = (lmin.z, rmin.z, lmax.x, rmax.x)
+//                  q2 = (lmax.y, rmax.y, lmax.z, rmax.z)  q3 = (lref, rref, 0, 0) as int bits
+//                (left/right interleaved: each register pair feeds one packed-f32 subtract / multiply of rayBox2)
 //                child reference: >= 0 inner-node index (BFS order over all objects, so the top
 //                levels are the first records = the LDS-staged tile); < 0 leaf whose first
 //                triangle record is -(ref+1); REF_EMPTY = leaf without triangles.
@@ -72,6 +73,29 @@ PM_DEV float rayBox(vec3 o, vec3 invD, float mnx, float mny, float mnz, float mx
     float tNear = maxnum(maxnum(t1x, t1y), t1z);
     float tFar = minnum(minnum(t2x, t2y), t2z);
     return (tFar >= tNear && tFar > 0.0f) ? (tNear > 0.0f ? tNear : 0.0f) : 1e30f;
+}
+
+// rayBox for the two children of a node at once.  Same binary32 operations per box as rayBox; the slab
+// subtractions and multiplications of the left and the right box are issued as packed-f32 pairs
+// (v_pk_add_f32 / v_pk_mul_f32: two IEEE results per instruction — the kernel is VALU-issue bound).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+PM_DEV void rayBox2(vec3 o, vec3 invD, float4 q0, float4 q1, float4 q2, float& Ld, float& Rd) {
+    f32x2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    f32x2 ix = {invD.x, invD.x}, iy = {invD.y, invD.y}, iz = {invD.z, invD.z};
+    f32x2 tminx = (f32x2{q0.x, q0.y} - ox) * ix, tminy = (f32x2{q0.z, q0.w} - oy) * iy, tminz = (f32x2{q1.x, q1.y} - oz) * iz;
+    f32x2 tmaxx = (f32x2{q1.z, q1.w} - ox) * ix, tmaxy = (f32x2{q2.x, q2.y} - oy) * iy, tmaxz = (f32x2{q2.z, q2.w} - oz) * iz;
+    {
+        float t1x = minnum(tminx.x, tmaxx.x), t1y = minnum(tminy.x, tmaxy.x), t1z = minnum(tminz.x, tmaxz.x);
+        float t2x = maxnum(tminx.x, tmaxx.x), t2y = maxnum(tminy.x, tmaxy.x), t2z = maxnum(tminz.x, tmaxz.x);
+        float tNear = maxnum(maxnum(t1x, t1y), t1z), tFar = minnum(minnum(t2x, t2y), t2z);
+        Ld = (tFar >= tNear && tFar > 0.0f) ? (tNear > 0.0f ? tNear : 0.0f) : 1e30f;
+    }
+    {
+        float t1x = minnum(tminx.y, tmaxx.y), t1y = minnum(tminy.y, tmaxy.y), t1z = minnum(tminz.y, tmaxz.y);
+        float t2x = maxnum(tminx.y, tmaxx.y), t2y = maxnum(tminy.y, tmaxy.y), t2z = maxnum(tminz.y, tmaxz.y);
+        float tNear = maxnum(maxnum(t1x, t1y), t1z), tFar = minnum(minnum(t2x, t2y), t2z);
+        Rd = (tFar >= tNear && tFar > 0.0f) ? (tNear > 0.0f ? tNear : 0.0f) : 1e30f;
+    }
 }
 
 // Moeller-Trumbore exactly as rayTri; returns 1e30 in t on a miss
@@ -160,8 +184,8 @@ PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int s
                 float4 q0, q1, q2, q3;
                 loadNode(sc, ldsN, ref, q0, q1, q2, q3);
                 if (COUNT) cnt.boxtests += 2;
-                float Ld = rayBox(o, invD, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-                float Rd = rayBox(o, invD, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                float Ld, Rd;
+                rayBox2(o, invD, q0, q1, q2, Ld, Rd);
                 int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                 bool pl = Ld < closest, pr = Rd < closest;
                 if (COUNT) { if (pl && lref == REF_EMPTY) cnt.nodes++; if (pr && rref == REF_EMPTY) cnt.nodes++; }

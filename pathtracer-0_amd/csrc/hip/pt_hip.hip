@@ -301,8 +301,8 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                 float4 q0, q1, q2, q3;
                 loadNode(sc, ldsN, cur, q0, q1, q2, q3);
                 if (COUNT) { c.nodes++; c.boxtests += 2; }
-                float Ld = rayBox(o, invD, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-                float Rd = rayBox(o, invD, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+                float Ld, Rd;
+                rayBox2(o, invD, q0, q1, q2, Ld, Rd);
                 int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                 bool pl = Ld < closest, pr = Rd < closest;
                 if (COUNT) { if (pl && lref == REF_EMPTY) c.nodes++; if (pr && rref == REF_EMPTY) c.nodes++; }
@@ -523,7 +523,8 @@ struct pt_ctx {
     std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; int* dAllMaps = nullptr;
     float4* dFrame = nullptr;
     // path pool
-    int poolSlots = 1 << 22; int allocSlots = 0; bool allocTrans = false;
+    int poolSlots = 0;              // 0 = automatic: jobs/8 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
+    int poolActive = 0; int allocSlots = 0; bool allocTrans = false;
     State st{};
     unsigned *dQueueA = nullptr, *dQueueB = nullptr, *dNQueue = nullptr;
     float4* dColbuf = nullptr; size_t colbufElems = 0;
@@ -661,7 +662,7 @@ int buildScene(pt_ctx* c) {
     for (int n : order) {
         int L = childOf(n, 0), R = childOf(n, 1);
         const float* A = c->bvhdata.data() + 8 * (size_t)L; const float* B = c->bvhdata.data() + 8 * (size_t)R;
-        nodeRecs.push_back(f4(A[0], A[1], A[2], A[3])); nodeRecs.push_back(f4(A[4], A[5], B[0], B[1])); nodeRecs.push_back(f4(B[2], B[3], B[4], B[5]));
+        nodeRecs.push_back(f4(A[0], B[0], A[1], B[1])); nodeRecs.push_back(f4(A[2], B[2], A[3], B[3])); nodeRecs.push_back(f4(A[4], B[4], A[5], B[5]));
         nodeRecs.push_back(f4(asf((uint32_t)refOf(L)), asf((uint32_t)refOf(R)), 0, 0));
     }
     std::vector<ObjRoot> roots(std::max(numObj, 1));
@@ -730,12 +731,12 @@ int buildScene(pt_ctx* c) {
 }
 
 int ensurePool(pt_ctx* c) {
-    if (c->allocSlots == c->poolSlots && c->allocTrans == c->trans) return 0;
+    if (c->allocSlots >= c->poolActive && c->allocTrans == c->trans) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H};
     for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
     for (unsigned** q : {&c->dQueueA, &c->dQueueB}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
-    size_t n = (size_t)c->poolSlots;
+    size_t n = (size_t)c->poolActive;
     for (int k = 0; k < 10; k++) {
         bool transOnly = (k >= 5 && k <= 8);
         if (transOnly && !c->trans) continue;
@@ -743,7 +744,7 @@ int ensurePool(pt_ctx* c) {
     }
     HIP_TRY(hipMalloc((void**)&c->dQueueA, n * 4));
     HIP_TRY(hipMalloc((void**)&c->dQueueB, n * 4));
-    c->allocSlots = c->poolSlots; c->allocTrans = c->trans;
+    c->allocSlots = c->poolActive; c->allocTrans = c->trans;
     return 0;
 }
 
@@ -807,6 +808,11 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     if (!(P[5] > 0.0f) || P[5] > 255.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,255]");
     size_t nJobs64 = (size_t)c->nLocal * (size_t)nFrames;
     if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
+    if (c->poolSlots > 0) c->poolActive = c->poolSlots;
+    else {
+        size_t want = std::min<size_t>(std::max<size_t>(nJobs64 / 8, (size_t)1 << 20), (size_t)1 << 22);
+        c->poolActive = (int)((std::min<size_t>(want, std::max<size_t>(nJobs64, BLOCK)) + BLOCK - 1) / BLOCK * BLOCK);
+    }
     if ((rc = ensurePool(c))) return rc;
     // per-batch inputs
     if (c->seedsCap < nFrames) { if (c->dSeeds) HIP_TRY(hipFree(c->dSeeds)); HIP_TRY(hipMalloc((void**)&c->dSeeds, (size_t)nFrames * 4)); c->seedsCap = nFrames; }
@@ -823,7 +829,7 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     Batch b;
     b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount; b.nJobs = (unsigned)nJobs64;
     b.firstFrame = firstFrame; b.nFrames = nFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.colbuf = c->dColbuf;
-    int N = c->poolSlots;
+    int N = c->poolActive;
     unsigned first = (unsigned)std::min<size_t>((size_t)N, nJobs64);
     hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first, (int)first);
     int gridN = (N + BLOCK - 1) / BLOCK;
@@ -1051,7 +1057,7 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
 int pt_set_option(pt_ctx* c, int option, int64_t value) {
     if (!c) return fail(PT_ERR_ARG, "null context");
     switch (option) {
-        case 0: if (value < BLOCK || value > (1 << 26)) return fail(PT_ERR_ARG, "path slots must be in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
+        case 0: if (value != 0 && (value < BLOCK || value > (1 << 26))) return fail(PT_ERR_ARG, "path slots must be 0 (automatic) or in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
         case 1: c->countStats = value != 0; return PT_OK;
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
         case 3: c->compactBelowPct = (int)value; return PT_OK;

@@ -52,6 +52,21 @@ def main(d):
             wl, ws = v["WRITE_SIZE"]
             n = max(fl, wl, 1)
             print(f"{k},{n},{fs/max(fl,1):.1f},{ws/max(wl,1):.1f},{(2*fs/max(fl,1)+ws/max(wl,1))*1024/1e6:.2f}")
+        # per-segment HBM traffic of the wavefront kernels (PMC runs: C3, 4 frames x 8 spp, S = 3.925 segments/sample)
+        seg = 1920 * 1080 * 32 * 3.925
+        out = {}
+        for k, v in agg.items():
+            base = k.split("<")[0]
+            if base in ("k_extend_persist", "k_extend", "k_shade"):
+                o = out.setdefault(base, {"fetch_kib_raw": 0.0, "write_kib": 0.0})
+                o["fetch_kib_raw"] += v["FETCH_SIZE"][1]
+                o["write_kib"] += v["WRITE_SIZE"][1]
+        for base, o in out.items():
+            o["hbm_bytes_per_segment"] = round((2 * o["fetch_kib_raw"] + o["write_kib"]) * 1024 / seg, 2)
+            print(f"per segment: {base} HBM bytes (FETCH x2 + WRITE) = {o['hbm_bytes_per_segment']}")
+        if len(sys.argv) > 2:
+            json.dump({"source": d, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); C3, 4 frames x 8 spp",
+                       "kernels": out}, open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":
