@@ -86,7 +86,7 @@ def main():
     r.load_workload(wl)
     r.reset_frame()
     packed = shard.frame_tensor(r, dev)
-    maps = torch.from_numpy(shard.all_maps(W, H, world, renderer.shard_map).astype(np.int64)).to(dev)
+    unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev)
 
     frame_no = [1]
 
@@ -100,7 +100,7 @@ def main():
             r.render_batch(first, [scenes.frame_seed(f) for f in range(first, first + n)])
             frame_no[0] += n
             done += n
-        return shard.gather_frame(packed, W, H, world, maps, dst=0)
+        return shard.gather_frame(packed, unshard, dst=0)
 
     def fence():
         if world > 1:

@@ -29,23 +29,35 @@ def all_maps(W, H, world, shard_map_fn):
     return np.concatenate([shard_map_fn(W, H, r, world) for r in range(world)])
 
 
-def gather_frame(packed, W, H, world, maps, dst=0, group=None):
+class Unsharder:
+    """Precomputed un-tiling: packed slot -> global pixel, built once so a step issues no host sync."""
+
+    def __init__(self, W, H, world, shard_map_fn, device):
+        maps = torch.from_numpy(all_maps(W, H, world, shard_map_fn).astype(np.int64))
+        self.W, self.H, self.world = W, H, world
+        self.src = torch.nonzero(maps >= 0).squeeze(1).to(device)          # packed slots that carry a pixel
+        self.dst = maps[maps >= 0].to(device)                               # their global pixel indices
+        self.identity = world == 1 and bool((self.src.cpu() == self.dst.cpu()).all())
+
+    def __call__(self, gathered):
+        if self.identity:
+            return gathered[: self.W * self.H].reshape(self.H, self.W, 4)
+        full = torch.empty((self.H * self.W, 4), dtype=gathered.dtype, device=gathered.device)
+        full.index_copy_(0, self.dst, gathered.index_select(0, self.src))
+        return full.reshape(self.H, self.W, 4)
+
+
+def gather_frame(packed, unsharder, dst=0, group=None):
     """ONE collective: gather every rank's packed accumulator (n_slots,4) on `dst`, then un-tile.
 
-    Returns the full (H, W, 4) image on rank `dst`, None elsewhere.  `maps` = all_maps(...) as a
-    torch int64 tensor on packed.device (built once)."""
-    rank = dist.get_rank(group) if world > 1 else 0
+    Returns the full (H, W, 4) image on rank `dst`, None elsewhere."""
+    world = unsharder.world
     if world == 1:
-        gathered = packed
-    else:
-        if rank == dst:
-            gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-            dist.gather(packed, list(gathered.unbind(0)), dst=dst, group=group)
-            gathered = gathered.reshape(-1, 4)
-        else:
-            dist.gather(packed, None, dst=dst, group=group)
-            return None
-    valid = maps >= 0
-    full = torch.zeros((H * W, 4), dtype=packed.dtype, device=packed.device)
-    full[maps[valid]] = gathered[valid]
-    return full.reshape(H, W, 4)
+        return unsharder(packed)
+    rank = dist.get_rank(group)
+    if rank == dst:
+        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        dist.gather(packed, list(gathered.unbind(0)), dst=dst, group=group)
+        return unsharder(gathered.reshape(-1, 4))
+    dist.gather(packed, None, dst=dst, group=group)
+    return None

@@ -1,0 +1,44 @@
+"""Worker for tests/test_gpu_parity.py::test_two_process_shards_on_one_gpu (launched by torch.distributed.run).
+
+Two ranks share cuda:0 (a one-GPU box), each renders its tile shard through the C ABI; the packed
+accumulators are gathered with gloo (RCCL refuses two ranks on one device) and un-tiled by the same
+shard.gather_frame() bench.py uses; rank 0 compares with its own unsharded render.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ptimport  # noqa: E402
+
+pt = ptimport.load()
+from pathtracer_0_amd import renderer, scenes, shard  # noqa: E402
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+W, H = 200, 120
+wl = scenes.build("C3", W, H)
+seeds = [scenes.frame_seed(f) for f in (1, 2, 3)]
+dev = torch.device("cuda", 0)
+r = renderer.Renderer(W, H, device=0, shard_rank=rank, shard_count=world)
+r.load_workload(wl)
+r.reset_frame()
+r.render_batch(1, seeds)
+r.synchronize()
+packed = shard.frame_tensor(r, dev).cpu()
+un = shard.Unsharder(W, H, world, renderer.shard_map, torch.device("cpu"))
+full = shard.gather_frame(packed, un, dst=0)
+if rank == 0:
+    r1 = renderer.Renderer(W, H, device=0)
+    r1.load_workload(wl); r1.reset_frame(); r1.render_batch(1, seeds)
+    ref = r1.read_frame()
+    r1.close()
+    assert np.array_equal(full.numpy(), ref), "sharded render differs from the unsharded one"
+    print("DIST_GPU_OK")
+r.close()
+dist.barrier()
+dist.destroy_process_group()

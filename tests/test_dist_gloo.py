@@ -35,8 +35,8 @@ def _worker(rank, world, port, W, H, out_path):
     m = renderer.shard_map(W, H, rank, world)
     packed = np.zeros((len(m), 4), np.float32)
     packed[m >= 0] = full.reshape(-1, 4)[m[m >= 0]]            # what this rank's renderer would hold
-    maps = torch.from_numpy(shard.all_maps(W, H, world, renderer.shard_map).astype(np.int64))
-    got = shard.gather_frame(torch.from_numpy(packed), W, H, world, maps, dst=0)
+    un = shard.Unsharder(W, H, world, renderer.shard_map, torch.device("cpu"))
+    got = shard.gather_frame(torch.from_numpy(packed), un, dst=0)
     if rank == 0:
         np.save(out_path, np.stack([got.numpy(), full]))
     else:

@@ -233,3 +233,13 @@ def test_full_size_properties_c3(pt, oracle, renderer_mod):
     for i, s in enumerate(seeds):
         oracle.render(sc, W, H, 1 + i, s, ref, nthreads=8, xs=24, ys=27)
     assert np.array_equal(a[::27, ::24], ref[::27, ::24])
+
+
+def test_two_process_shards_on_one_gpu(pt):
+    """one process per shard (as on the 8-GPU node), here 2 ranks sharing cuda:0, gloo collective"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          os.path.join(root, "tests", "_dist_gpu_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
