@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--extend-tpb", type=int, default=None)
     ap.add_argument("--extend-cache", type=int, default=None)
     ap.add_argument("--refill-min", type=int, default=None)
+    ap.add_argument("--extend-blocks-per-cu", type=int, default=None)
+    ap.add_argument("--rehearse-shard", type=int, nargs=2, metavar=("RANK", "COUNT"), default=None,
+                    help="single-process rehearsal of ONE tile shard of a COUNT-GPU run (no collective); reports that shard's rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
     args = ap.parse_args()
@@ -72,12 +75,14 @@ def main():
     spp_step = fps * sample_res
     wl = scenes.build(args.config, W, H)
 
-    r = renderer.Renderer(W, H, device=local_rank, shard_rank=rank, shard_count=world)
+    shard_rank, shard_count = (rank, world) if not args.rehearse_shard else tuple(args.rehearse_shard)
+    r = renderer.Renderer(W, H, device=local_rank, shard_rank=shard_rank, shard_count=shard_count)
     if args.path_slots:
         r.set_option("path_slots", args.path_slots)
     if args.lds_budget is not None:
         r.set_option("lds_budget", args.lds_budget)
-    for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min)):
+    for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min),
+                      ("extend_blocks_per_cu", args.extend_blocks_per_cu)):
         if val is not None:
             r.set_option(name, val)
     stream = torch.cuda.Stream(dev)             # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
@@ -86,7 +91,9 @@ def main():
     r.load_workload(wl)
     r.reset_frame()
     packed = shard.frame_tensor(r, dev)
-    unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev)
+    unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev) if not args.rehearse_shard else (lambda t: t)
+    if args.rehearse_shard:
+        unshard.world = 1
 
     frame_no = [1]
 
@@ -139,6 +146,8 @@ def main():
         dt = float(t.item())
 
     samples = float(W) * H * spp_step * args.steps
+    if args.rehearse_shard:
+        samples = float((renderer.shard_map(W, H, shard_rank, shard_count) >= 0).sum()) * spp_step * args.steps
     value = samples / dt / 1e6
 
     out = {
@@ -150,6 +159,8 @@ def main():
                    "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"]},
     }
 
+    if args.rehearse_shard:
+        out["rehearsal"] = f"shard {shard_rank} of {shard_count} alone on one GPU: value is THIS shard's rate, not a multi-GPU measurement"
     if stats is not None:
         n_ext, ms_ext = r.kernel_time("extend")
         n_sh, ms_sh = r.kernel_time("shade")

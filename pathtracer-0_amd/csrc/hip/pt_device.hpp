@@ -257,7 +257,8 @@ struct Path {
     vec3 O, D;             // current ray
     vec3 col, inc;         // throughput, incLight of the current sample
     vec3 sum;              // sum of samples of the current pixel-frame
-    uint32_t rng, job;
+    uint32_t rng;
+    uint32_t pix, fi, ls;  // job identity: global pixel (x | y<<16), frame slot of the batch, accumulator slot
     int bounce, sample, stackSize;
     bool inObj, applyAbs, alive;
     vec3 enter; float dist;   // RAY_ENTER_LOCATION, DISTANCE_TRAVELED

@@ -61,9 +61,11 @@ struct State {              // SoA path pool, float4 groups (see header comment)
 struct Batch {
     int W, H, nLocal, nSlots, shardCount;
     unsigned nJobs;
+    unsigned divM, divS;      // job / nLocal == mulhi(job, divM) >> divS for job < 2^31 (nLocal >= 2); divM == 0: nLocal == 1
     int firstFrame, nFrames;
     const int* seeds;         // device, nFrames
     const int* pixList;       // device, nLocal: global pixel index in tile-major job order
+    const unsigned* pixXY;    // device, nLocal: the same pixels as x | y << 16
     float4* colbuf;           // nFrames * nSlots
 };
 
@@ -116,9 +118,9 @@ __global__ void k_frame_setup(DevScene sc, const FrameIn* in, FrameConst* fc, El
 __device__ __forceinline__ void storePath(const State& st, unsigned i, const Path& p, bool trans) {
     st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
     st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
-    st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.job));
-    st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f);
-    st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, 0.0f);
+    st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.pix));
+    st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
+    st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.ls));
     if (trans) {
         st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
         st.S0[i] = make_float4(p.s[0], p.s[1], p.s[2], p.s[3]);
@@ -130,12 +132,14 @@ __device__ __forceinline__ void storePath(const State& st, unsigned i, const Pat
 // A new pixel-frame job (one fragment-shader invocation): fresh "globals" (SURVEY.md Q-1), rngState = index + u_seed.
 // The caller follows up with startSample (kept separate so that k_shade has a single startSample site).
 __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, unsigned job, Path& p) {
-    unsigned fi = job / (unsigned)b.nLocal, k = job - fi * (unsigned)b.nLocal;
-    int gp = b.pixList[k];
-    int px = gp % b.W, py = gp / b.W;
+    unsigned fi = b.divM ? (__umulhi(job, b.divM) >> b.divS) : job;      // job / nLocal without an integer division
+    unsigned k = job - fi * (unsigned)b.nLocal;
+    unsigned xy = b.pixXY[k];
+    int px = (int)(xy & 0xffffu), py = (int)(xy >> 16);
     uint32_t index;
     pixelIndex(fc, b.W, b.H, px, py, index);
-    p.job = job;
+    p.pix = xy; p.fi = fi;
+    p.ls = (b.shardCount == 1) ? (unsigned)(py * b.W + px) : k;
     p.rng = index + (uint32_t)b.seeds[fi];
     p.sum = v3(0.0f);
     p.sample = 0;
@@ -155,11 +159,10 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Batch b, const FrameConst* f
     Path p;
     if (i < b.nJobs) {
         startJob(b, fc, i, p);
-        int gp = b.pixList[i % (unsigned)b.nLocal];
-        startSample(fc, b.W, b.H, gp % b.W, gp / b.W, p);
+        startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
     } else {
         p = Path();
-        p.alive = false; p.job = 0; p.rng = 0; p.bounce = 0; p.sample = 0; p.stackSize = 0; p.inObj = false; p.applyAbs = false;
+        p.alive = false; p.pix = 0; p.fi = 0; p.ls = 0; p.rng = 0; p.bounce = 0; p.sample = 0; p.stackSize = 0; p.inObj = false; p.applyAbs = false;
         p.O = p.D = p.col = p.inc = p.sum = p.enter = v3(0.0f); p.dist = 0.0f;
         for (int k = 0; k < 10; k++) p.s[k] = 0.0f;
     }
@@ -371,8 +374,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
     if (live) {
         float4 g0 = st.G0[i], g2 = st.G2[i], g3 = st.G3[i], g4 = st.G4[i], h = st.H[i];
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
-        p.col = v3(g2.x, g2.y, g2.z); p.job = __float_as_uint(g2.w);
-        p.inc = v3(g3.x, g3.y, g3.z); p.sum = v3(g4.x, g4.y, g4.z);
+        p.col = v3(g2.x, g2.y, g2.z); p.pix = __float_as_uint(g2.w);
+        p.inc = v3(g3.x, g3.y, g3.z); p.fi = __float_as_uint(g3.w);
+        p.sum = v3(g4.x, g4.y, g4.z); p.ls = __float_as_uint(g4.w);
         if (TRANS) {
             float4 g5 = st.G5[i], s0 = st.S0[i], s1 = st.S1[i], s2 = st.S2[i];
             p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w;
@@ -390,10 +394,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
             if ((float)p.sample < fc.SAMPLE_RES) {                 // loop condition :898
                 needStart = true;
             } else {
-                unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
-                unsigned ls = (b.shardCount == 1) ? (unsigned)b.pixList[k] : k;
                 float sr = fc.SAMPLE_RES;
-                b.colbuf[(size_t)fi * b.nSlots + ls] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
+                b.colbuf[(size_t)p.fi * b.nSlots + p.ls] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
                 jobDone = true;
             }
         }
@@ -422,9 +424,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         else p.alive = false;
     }
     if (needStart) {                                              // the single camera-ray site: next sample of the job, or first of a new one
-        unsigned fi = p.job / (unsigned)b.nLocal, k = p.job - fi * (unsigned)b.nLocal;
-        int gp = b.pixList[k];
-        startSample(fc, b.W, b.H, gp % b.W, gp / b.W, p);
+        startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
     }
     unsigned long long dead = __ballot(jobDone && !p.alive);
     if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
@@ -520,10 +520,10 @@ struct pt_ctx {
     float4* dSky = nullptr;
     DevScene sc{};
     // shard
-    std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; int* dAllMaps = nullptr;
+    std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; unsigned* dPixXY = nullptr; int* dAllMaps = nullptr;
     float4* dFrame = nullptr;
     // path pool
-    int poolSlots = 0;              // 0 = automatic: jobs/8 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
+    int poolSlots = 0;              // 0 = automatic: jobs/5 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
     int poolActive = 0; int allocSlots = 0; bool allocTrans = false;
     State st{};
     unsigned *dQueueA = nullptr, *dQueueB = nullptr, *dNQueue = nullptr;
@@ -537,7 +537,7 @@ struct pt_ctx {
     int ldsBudget = 20 * 1024;
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
     int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
-    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0;
+    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 3;
     int compactBelowPct = 70;       // compact the queue when fewer than this % of the launched lanes are live
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; } kt[4];
@@ -782,6 +782,7 @@ void launchExtendPersist(pt_ctx* c, const unsigned* queue, int launched) {
     size_t lds = (size_t)sc.ldsNodes * 64 + (size_t)sc.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
     int perCU = std::max(1, std::min((int)(160 * 1024 / std::max<size_t>(lds, 1)), 2048 / tpb));
+    if (c->extendMaxBlocksPerCU > 0) perCU = std::min(perCU, c->extendMaxBlocksPerCU);
     int grid = c->numCUs * perCU;
     int maxUseful = (launched + tpb - 1) / tpb;                  // never more blocks than 1 lane per ray
     grid = std::max(1, std::min(grid, maxUseful));
@@ -810,7 +811,7 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
     if (c->poolSlots > 0) c->poolActive = c->poolSlots;
     else {
-        size_t want = std::min<size_t>(std::max<size_t>(nJobs64 / 8, (size_t)1 << 20), (size_t)1 << 22);
+        size_t want = std::min<size_t>(std::max<size_t>(nJobs64 / 5, (size_t)1 << 20), (size_t)1 << 22);
         c->poolActive = (int)((std::min<size_t>(want, std::max<size_t>(nJobs64, BLOCK)) + BLOCK - 1) / BLOCK * BLOCK);
     }
     if ((rc = ensurePool(c))) return rc;
@@ -828,7 +829,13 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
 
     Batch b;
     b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount; b.nJobs = (unsigned)nJobs64;
-    b.firstFrame = firstFrame; b.nFrames = nFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.colbuf = c->dColbuf;
+    b.firstFrame = firstFrame; b.nFrames = nFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
+    if (c->nLocal >= 2) {                                     // ceil(2^(31+l)/d), exact for every job < 2^31
+        unsigned d = (unsigned)c->nLocal; int l = 0;
+        while ((1ull << l) < d) l++;
+        unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;
+        b.divM = (unsigned)m; b.divS = (unsigned)(l - 1);
+    } else { b.divM = 0; b.divS = 0; }
     int N = c->poolActive;
     unsigned first = (unsigned)std::min<size_t>((size_t)N, nJobs64);
     hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first, (int)first);
@@ -899,7 +906,7 @@ extern "C" {
 const char* pt_last_error(void) { return g_err.c_str(); }
 
 int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count) {
-    if (!out || width < 1 || height < 1 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(PT_ERR_ARG, "pt_create: bad argument");
+    if (!out || width < 1 || height < 1 || width > 65535 || height > 65535 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(PT_ERR_ARG, "pt_create: bad argument");
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= nDev) return fail(PT_ERR_NO_DEVICE, "HIP device index out of range");
@@ -918,6 +925,12 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
     if (c->nLocal == 0) { delete c; return fail(PT_ERR_ARG, "this shard owns no pixels (more shards than tiles)"); }
     HIP_TRY(hipMalloc((void**)&c->dPixList, (size_t)c->nLocal * 4));
     HIP_TRY(hipMemcpy(c->dPixList, c->pixList.data(), (size_t)c->nLocal * 4, hipMemcpyHostToDevice));
+    {
+        std::vector<unsigned> xy(c->pixList.size());
+        for (size_t k = 0; k < xy.size(); k++) xy[k] = (unsigned)(c->pixList[k] % width) | ((unsigned)(c->pixList[k] / width) << 16);
+        HIP_TRY(hipMalloc((void**)&c->dPixXY, xy.size() * 4));
+        HIP_TRY(hipMemcpy(c->dPixXY, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMalloc((void**)&c->dFrame, (size_t)c->nSlotsImg * 16));
     HIP_TRY(hipMemset(c->dFrame, 0, (size_t)c->nSlotsImg * 16));
     HIP_TRY(hipMalloc((void**)&c->dFrameIn, sizeof(FrameIn)));
@@ -937,7 +950,7 @@ int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
+    void* ptrs[] = {c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hAlive) hipHostFree(c->hAlive);
@@ -1065,6 +1078,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
+        case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");
 }

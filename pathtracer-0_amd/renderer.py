@@ -18,13 +18,13 @@ _LIB = None
 COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "iterations", "extend_launches"]
 KERNELS = {"extend": 0, "shade": 1, "generate": 2, "accumulate": 3}
 OPTIONS = {"path_slots": 0, "count_stats": 1, "lds_budget": 2, "compact_below_pct": 3, "extend_mode": 4, "extend_tpb": 5, "extend_cache_bytes": 6,
-           "refill_min": 7}
+           "refill_min": 7, "extend_blocks_per_cu": 8}
 
 
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libpt_hip.so")
+        path = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "libpt_hip.so")     # PT_HIP_LIB: A/B builds of the same ABI (tuning only)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: the HIP extension is required (no fallback). Build it with __graft_entry__.build()")
         L = C.CDLL(path)
