@@ -186,6 +186,7 @@ def main():
                            "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3), "bytes": round(bytes_per_seg_extend, 1)},
                            "segments_per_sample": round(S, 3), "bytes_per_sample_whole_path": round(bytes_per_sample, 1),
                            "whole_path_GBps": round(bytes_per_sample * value * 1e6 / 1e9 / world, 1),
+                           "median_launch_ms": round(r.kernel_time_median("extend"), 4), "shade_median_launch_ms": round(r.kernel_time_median("shade"), 4),
                            "shade_avg_launch_ms": round(ms_sh / max(n_sh, 1), 4), "extend_share_of_step": round(ms_ext / (dt * 1e3), 3),
                            "shade_share_of_step": round(ms_sh / (dt * 1e3), 3)}
 

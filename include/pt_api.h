@@ -118,6 +118,8 @@ int pt_reset_counters(pt_ctx* ctx);
  * Synchronises.  launches = number of launches, total_ms = summed duration. */
 int pt_kernel_time(pt_ctx* ctx, int kernel, int64_t* launches, double* total_ms);
 int pt_set_timing(pt_ctx* ctx, int enabled);
+/* median launch duration of that kernel (steady-state figure: the mean also averages the short launches of a batch's tail) */
+int pt_kernel_time_median(pt_ctx* ctx, int kernel, double* median_ms);
 
 /* Debug / parity probes (used by tests): evaluates the device numeric contract.
  * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; host pointers, n elements. */

@@ -263,6 +263,7 @@ struct Path {
     bool inObj, applyAbs, alive;
     vec3 enter; float dist;   // RAY_ENTER_LOCATION, DISTANCE_TRAVELED
     float s[10];           // refractionIndiceStack
+    bool g5loaded, g5dirty; // lazily fetched / modified (enter, dist) group, see k_shade
 };
 
 PM_DEV uint32_t packFlags(const Path& p) {
@@ -362,21 +363,28 @@ PM_DEV vec3 lobeDirection(int w, vec3 G, vec3 N, vec3 D, float eta, float Pcr) {
     return rough;                                                                 // :795-804
 }
 
-// Sample set-up of main(), frag.glsl:885-910, for global pixel (px,py): new camera ray + trace() prologue (:811-818).
-PM_DEV void startSample(const FrameConst& fc, int W, int H, int px, int py, Path& p) {
+// Camera ray of one sample, main() frag.glsl:894-908, for global pixel (px,py): lens jitter (6 RNG draws), focus, normalise.
+PM_DEV void cameraRay(const FrameConst& fc, int W, int H, int px, int py, uint32_t& rng, vec3& O, vec3& D) {
     float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
     vec3 q = v3(((tcx * 2.0f - 1.0f) * -1.0f) * fc.screenSize, ((tcy * 2.0f - 1.0f) * fc.screenHratio) * fc.screenSize, fc.focalLength);
     vec3 direction = vecmat(q, fc.camRot);
     vec3 ORIGIN = v3(fc.origin[0], fc.origin[1], fc.origin[2]);
-    vec3 origin_jittered = ORIGIN + vecmat(randLambertianDistVec(p.rng) * fc.BLUR, fc.camRot);
+    vec3 origin_jittered = ORIGIN + vecmat(randLambertianDistVec(rng) * fc.BLUR, fc.camRot);
     vec3 focal_point = ORIGIN + direction * fc.focus;
-    p.D = normalize(focal_point - origin_jittered);
-    p.O = origin_jittered;
+    D = normalize(focal_point - origin_jittered);
+    O = origin_jittered;
+}
+// trace() prologue (:811-818): everything a new sample resets that needs no random numbers
+PM_DEV void tracePrologue(Path& p) {
     p.col = v3(1.0f); p.inc = v3(0.0f);
     p.stackSize = 0;                       // clearIndiceStack
     addToIndiceStack(p, 1.0029f);
     p.inObj = false;
     p.bounce = 0;
+}
+PM_DEV void startSample(const FrameConst& fc, int W, int H, int px, int py, Path& p) {
+    cameraRay(fc, W, H, px, py, p.rng, p.O, p.D);
+    tracePrologue(p);
 }
 
 // rngState = index + u_seed (:886,:896) for global pixel (px,py); false when the fragment returns early (:887)
@@ -394,7 +402,7 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
 // One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
 // Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
 template <bool TRANS>
-PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim) {
+PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, unsigned slot) {
     p.bounce++;                                               // :821
     const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
     const vec3 D = p.D;
@@ -438,6 +446,8 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
     }
     p.D = lobeDirection(w, G, N, D, n1 / n2, Pcr);
     if (TRANS && w == 3) {                                    // :847-863
+        if (!p.g5loaded) { float4 g5 = G5[slot]; p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; }   // only transmission touches it
+        p.g5dirty = true;
         if (ND < 0.0f) {
             if (p.inObj) { p.dist = distance(p.enter, p.O); p.applyAbs = true; }
             p.inObj = true;

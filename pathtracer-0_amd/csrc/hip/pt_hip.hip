@@ -356,37 +356,77 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     }
 }
 
-// trace() loop body + sample/job bookkeeping for every live path slot
+// trace() loop body + sample/job bookkeeping for every live path slot.
+// The kernel is VALU-issue bound and its three big instruction streams are taken by different lanes (hit shading
+// ~75 %, sky ~25 %, new camera ray ~25-30 %), so the block first SORTS its 256 slots by outcome through LDS
+// (wave64 ballot + prefix popcount per wave, 4-wave scan): hits first, misses next, dead slots last.  Waves then
+// run one stream each.  Camera rays (6 Gaussian draws + transforms, the heaviest piece) are not computed by the lane
+// that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes all parked
+// rays densely after a barrier.
 template <bool TRANS, bool STATS>
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
                                                  int nSlots, Control* ctl) {
-    unsigned n = queue ? *nQueue : (unsigned)nSlots;
-    unsigned q = blockIdx.x * BLOCK + threadIdx.x;
-    bool valid = q < n;
-    unsigned i = valid ? (queue ? queue[q] : q) : 0;
+    __shared__ unsigned sPerm[BLOCK], sFlags[BLOCK];
+    __shared__ uint4 sRegen[BLOCK];
+    __shared__ unsigned sCntA[BLOCK / 64], sCntB[BLOCK / 64], sBase, sRegenCount;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
     const FrameConst& fc = *fcp;
+    const unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    // ---- 1. classify own slot, 2. block-level partition
+    {
+        unsigned q = blockIdx.x * BLOCK + threadIdx.x;
+        bool valid = q < n;
+        unsigned i = valid ? (queue ? queue[q] : q) : 0;
+        const unsigned fl = valid ? __float_as_uint(st.G1[i].w) : 0u;
+        bool alive = valid && (fl & FL_ALIVE);
+        bool isHit = false;
+        if (alive) { float4 h = st.H[i]; isHit = !(__float_as_int(h.w) == PRIM_NONE || !(h.x < 1e25f)); }
+        bool isMiss = alive && !isHit;
+        unsigned long long mh = __ballot(isHit), mm = __ballot(isMiss);
+        if (lane == 0) { sCntA[wave] = (unsigned)__popcll(mh); sCntB[wave] = (unsigned)__popcll(mm); }
+        if (threadIdx.x == 0) sRegenCount = 0;
+        __syncthreads();
+        unsigned nHit = 0, hBefore = 0, mBefore = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) { nHit += sCntA[w]; if (w < wave) { hBefore += sCntA[w]; mBefore += sCntB[w]; } }
+        sPerm[threadIdx.x] = 0xffffffffu;
+        __syncthreads();
+        if (isHit) { unsigned k = hBefore + (unsigned)__popcll(mh & ltMask); sPerm[k] = i; sFlags[k] = fl; }
+        if (isMiss) { unsigned k = nHit + mBefore + (unsigned)__popcll(mm & ltMask); sPerm[k] = i; sFlags[k] = fl; }
+        __syncthreads();
+    }
+    // ---- 3. shade the slot this thread was dealt
+    const unsigned i = sPerm[threadIdx.x];
+    const bool live = i != 0xffffffffu;
     Path p;
-    float4 g1 = valid ? st.G1[i] : make_float4(0, 0, 0, 0);
-    unpackFlags(p, __float_as_uint(g1.w));
-    bool live = valid && p.alive;
+    p.alive = false;
     bool jobDone = false, needStart = false;
     unsigned nSamp = 0;
+    // Groups are written back only when this segment changed them: sum (G4) at sample end; RAY_ENTER_LOCATION /
+    // DISTANCE_TRAVELED (G5) when the transmission lobe won; index-stack slots 4-7 / 8-9 (S1/S2) are not even fetched
+    // unless the stack is that deep (push/pop never touch slots above the current size, frag.glsl:142-158).
+    bool touchS1 = false, touchS2 = false, sampleDone = false, newJob = false;
     if (live) {
-        float4 g0 = st.G0[i], g2 = st.G2[i], g3 = st.G3[i], g4 = st.G4[i], h = st.H[i];
+        // every load of the segment is issued here, in one batch (the flags came through LDS): the kernel's critical path
+        // is memory round trips, not bytes
+        unpackFlags(p, sFlags[threadIdx.x]);
+        float4 g0 = st.G0[i], g1 = st.G1[i], g2 = st.G2[i], g3 = st.G3[i], h = st.H[i], g4 = st.G4[i];
+        float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, g5 = s0;
+        if (TRANS) {
+            s0 = st.S0[i];
+            touchS1 = p.stackSize >= 4; touchS2 = p.stackSize >= 8;
+            if (touchS1) s1 = st.S1[i];
+            if (touchS2) s2 = st.S2[i];
+            g5 = st.G5[i];
+        }
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
         p.col = v3(g2.x, g2.y, g2.z); p.pix = __float_as_uint(g2.w);
         p.inc = v3(g3.x, g3.y, g3.z); p.fi = __float_as_uint(g3.w);
         p.sum = v3(g4.x, g4.y, g4.z); p.ls = __float_as_uint(g4.w);
-        if (TRANS) {
-            float4 g5 = st.G5[i], s0 = st.S0[i], s1 = st.S1[i], s2 = st.S2[i];
-            p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w;
-            p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
-        } else {
-            p.enter = v3(0.0f); p.dist = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 10; k++) p.s[k] = 0.0f;
-        }
-        bool sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w));
+        p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; p.g5dirty = false;
+        p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
+        sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, i);
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
             p.sample++;
@@ -400,35 +440,52 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
             }
         }
     }
-    // job pull: wave64 ballot + prefix count, aggregated once more over the block's 4 waves through LDS, so
-    // the scheduler word sees ONE atomic per 256 lanes per launch (a single address sustains only ~90 atomics/us)
-    __shared__ unsigned sCnt[BLOCK / 64];
-    __shared__ unsigned sBase;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- 4. job pull: ballot + prefix count per wave, aggregated over the block's 4 waves through LDS, so the
+    // scheduler word sees ONE atomic per 256 lanes per launch (a single address sustains only ~90 atomics/us)
     unsigned long long mask = __ballot(jobDone);
-    if (lane == 0) sCnt[wave] = (unsigned)__popcll(mask);
+    if (lane == 0) sCntA[wave] = (unsigned)__popcll(mask);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned total = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) total += sCnt[w];
+        for (int w = 0; w < BLOCK / 64; w++) total += sCntA[w];
         sBase = total ? atomicAdd(&ctl->nextJob, total) : 0u;
     }
     __syncthreads();
     if (jobDone) {
         unsigned off = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) off += (w < wave) ? sCnt[w] : 0u;
-        unsigned job = sBase + off + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-        if (job < b.nJobs) { startJob(b, fc, job, p); needStart = true; }
+        for (int w = 0; w < BLOCK / 64; w++) off += (w < wave) ? sCntA[w] : 0u;
+        unsigned job = sBase + off + (unsigned)__popcll(mask & ltMask);
+        if (job < b.nJobs) { startJob(b, fc, job, p); needStart = true; newJob = true; }
         else p.alive = false;
-    }
-    if (needStart) {                                              // the single camera-ray site: next sample of the job, or first of a new one
-        startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
     }
     unsigned long long dead = __ballot(jobDone && !p.alive);
     if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
-    if (live) storePath(st, i, p, TRANS);
+    // ---- 5. store; lanes that start a sample do the prologue themselves and park the camera ray for the dense pass
+    if (needStart) tracePrologue(p);
+    unsigned long long ms = __ballot(needStart);
+    unsigned rbase = 0;
+    if (ms) {
+        if (lane == (__ffsll((long long)ms) - 1)) rbase = atomicAdd(&sRegenCount, (unsigned)__popcll(ms));
+        rbase = __shfl(rbase, __ffsll((long long)ms) - 1);
+    }
+    if (needStart) sRegen[rbase + (unsigned)__popcll(ms & ltMask)] = make_uint4(i, p.rng, p.pix, packFlags(p));
+    if (live) {
+        if (!needStart) {                                          // parked slots get O, D, rng, flags from the dense pass below
+            st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
+            st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
+        }
+        st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.pix));
+        st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
+        if (sampleDone) st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.ls));
+        if (TRANS) {
+            st.S0[i] = make_float4(p.s[0], p.s[1], p.s[2], p.s[3]);
+            if (touchS1 || newJob) st.S1[i] = make_float4(p.s[4], p.s[5], p.s[6], p.s[7]);
+            if (touchS2 || newJob) st.S2[i] = make_float4(p.s[8], p.s[9], 0.0f, 0.0f);
+            if (p.g5dirty || newJob) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
+        }
+    }
     if (STATS) {                                  // statistics (count mode only): one atomic per wave
         unsigned long long lm = __ballot(live);
         unsigned long long sm = __ballot(nSamp != 0);
@@ -436,6 +493,17 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
             atomicAdd(&ctl->cnt[PT_CNT_SEGMENTS], (unsigned long long)__popcll(lm));
             if (sm) atomicAdd(&ctl->cnt[PT_CNT_SAMPLES], (unsigned long long)__popcll(sm));
         }
+    }
+    __syncthreads();
+    // ---- 6. dense camera-ray pass (frag.glsl:899-908): overwrites O, D, rngState of the parked slots
+    const unsigned nRegen = sRegenCount;
+    for (unsigned k = threadIdx.x; k < nRegen; k += BLOCK) {
+        uint4 e = sRegen[k];
+        uint32_t rng = e.y;
+        vec3 O, D;
+        cameraRay(fc, b.W, b.H, (int)(e.z & 0xffffu), (int)(e.z >> 16), rng, O, D);
+        st.G0[e.x] = make_float4(O.x, O.y, O.z, D.x);
+        st.G1[e.x] = make_float4(D.y, D.z, __uint_as_float(rng), __uint_as_float(e.w));
     }
 }
 
@@ -540,7 +608,7 @@ struct pt_ctx {
     bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 3;
     int compactBelowPct = 70;       // compact the queue when fewer than this % of the launched lanes are live
     uint64_t hostCnt[PT_CNT_N] = {0};
-    struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; } kt[4];
+    struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
 };
 
 namespace {
@@ -850,7 +918,11 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     int alive = (int)first;
     uint64_t iters = 0;
     const int CHECK = 8;
+    // every job retires within SAMPLE_RES * ceil(MAX_BOUNCES) iterations of being started, and a slot runs at most
+    // ceil(jobs / slots) jobs back to back: a batch that exceeds this bound (x2) is a scheduler bug, not work
+    const uint64_t maxIters = 2 * ((nJobs64 + first - 1) / first + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
     while (alive > 0) {
+        if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
         for (int k = 0; k < CHECK; k++) {
             int grid = (int)((launched + BLOCK - 1) / BLOCK);
             if (c->extendMode == 0) {
@@ -890,7 +962,7 @@ int resolveTimes(pt_ctx* c) {
         for (size_t i = 0; i < k.used; i++) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, k.ev[i].first, k.ev[i].second));
-            k.ms += ms; k.launches++;
+            k.ms += ms; k.launches++; k.each.push_back(ms);
         }
         k.used = 0;
     }
@@ -1102,7 +1174,7 @@ int pt_reset_counters(pt_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
     std::memset(c->hostCnt, 0, sizeof(c->hostCnt));
-    for (auto& k : c->kt) { k.used = 0; k.ms = 0; k.launches = 0; }
+    for (auto& k : c->kt) { k.used = 0; k.ms = 0; k.launches = 0; k.each.clear(); }
     return PT_OK;
 }
 
@@ -1115,6 +1187,19 @@ int pt_kernel_time(pt_ctx* c, int kernel, int64_t* launches, double* total_ms) {
     int rc = resolveTimes(c);
     if (rc) return rc;
     *launches = c->kt[kernel].launches; *total_ms = c->kt[kernel].ms;
+    return PT_OK;
+}
+
+int pt_kernel_time_median(pt_ctx* c, int kernel, double* median_ms) {
+    if (!c || kernel < 0 || kernel > 3 || !median_ms) return fail(PT_ERR_ARG, "pt_kernel_time_median: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int rc = resolveTimes(c);
+    if (rc) return rc;
+    std::vector<float> v = c->kt[kernel].each;
+    if (v.empty()) { *median_ms = 0; return PT_OK; }
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    *median_ms = v[v.size() / 2];
     return PT_OK;
 }
 

@@ -49,6 +49,7 @@ def lib():
         L.pt_reset_counters.argtypes = [vp]
         L.pt_kernel_time.argtypes = [vp, ci, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.pt_set_timing.argtypes = [vp, ci]
+        L.pt_kernel_time_median.argtypes = [vp, ci, C.POINTER(C.c_double)]
         L.pt_debug_math.argtypes = [vp, ci, vp, vp, vp, sz]
         L.pt_debug_intersect.argtypes = [vp, vp, vp, vp, sz]
         _LIB = L
@@ -166,6 +167,11 @@ class Renderer:
         n, ms = C.c_int64(), C.c_double()
         _check(self._L.pt_kernel_time(self._h, KERNELS[name], C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def kernel_time_median(self, name):
+        ms = C.c_double()
+        _check(self._L.pt_kernel_time_median(self._h, KERNELS[name], C.byref(ms)))
+        return ms.value
 
     # --- parity probes --------------------------------------------------------------------------
     def debug_math(self, fn, x, y=None):

@@ -9,7 +9,7 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d.get('roofline',{})
-        print('$lib round $round ->', d['value'], 'Ms/s  ext_ms', r.get('avg_launch_ms'), 'shade_ms', r.get('shade_avg_launch_ms'))
+        print('$lib round $round ->', d['value'], 'Ms/s  ext avg/med', r.get('avg_launch_ms'), r.get('median_launch_ms'), 'shade avg/med', r.get('shade_avg_launch_ms'), r.get('shade_median_launch_ms'))
 "
  done
 done
