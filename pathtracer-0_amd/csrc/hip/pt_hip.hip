@@ -210,11 +210,16 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 //    goes through the LDS stack.
 // Per ray the sequence of visited nodes / tested triangles and every comparison are exactly rayBVH's (frag.glsl:
 // 452-537): a lane never steps past a pending leaf, so `closest` evolves in the reference's order.
-constexpr int CUR_NONE = 0x7fffffff;
+// `cur` = the entry this lane will process next (the virtual top of rayBVH's stack):
+//   >= 0 and < CUR_NONE  inner node   |   < 0  leaf: first triangle record is -(cur+1)
+//   CUR_NONE  ray alive, BVH of the current object exhausted   |   CUR_IDLE  lane has no ray
+// (activity is folded into `cur` so that every wave-level vote is ONE v_cmp writing an SGPR pair)
+constexpr int CUR_NONE = 0x7ffffffe;
+constexpr int CUR_IDLE = 0x7fffffff;
 
 template <bool COUNT, typename StackT, int TPB>
 __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* queue, const unsigned* nQueue, int nSlots,
-                                                       Control* ctl, int refillMin, int stackDepth, int nObjLds) {
+                                                       Control* ctl, int refillMin, int keepEighths, int nObjLds) {
     extern __shared__ float4 smem[];
     float4* ldsN = smem;
     float4* ldsT = smem + 4 * sc.ldsNodes;
@@ -222,7 +227,6 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     // when the lane takes the ray — all refilled lanes together — and only compared against `closest` later)
     float* rootDist = reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + threadIdx.x;
     StackT* stk = reinterpret_cast<StackT*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB) + threadIdx.x;
-    (void)stackDepth;
     for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += TPB) ldsN[k] = sc.nodes[k];
     for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += TPB) ldsT[k] = sc.tris[k];
     __syncthreads();
@@ -233,18 +237,17 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     const unsigned per = (((n + nWaves - 1) / nWaves) + 63u) & ~63u;       // static range of this wave, 64-aligned -> coalesced first fill
     unsigned pos = waveId * per;
     const unsigned end = min(pos + per, n);
-    bool active = false;
     vec3 o = v3(0.0f), d = v3(0.0f), invD = v3(0.0f);
     float closest = 1e30f, hu = 0.0f, hv = 0.0f;
-    int prim = PRIM_NONE, ob = 0, sp = 0, cur = CUR_NONE;
+    int prim = PRIM_NONE, ob = 0, sp = 0, cur = CUR_IDLE;
     unsigned slot = 0;
     Counters c;
     for (;;) {
         // ---- refill idle lanes from the wave's range
-        unsigned long long idle = __ballot(!active);
+        unsigned long long idle = __ballot(cur == CUR_IDLE);
         int nIdle = __popcll(idle);
         if (pos < end && nIdle >= refillMin) {                              // wave-uniform
-            if (!active) {
+            if (cur == CUR_IDLE) {
                 unsigned q = pos + (unsigned)__popcll(idle & ltMask);
                 if (q < end) {
                     slot = queue ? queue[q] : q;
@@ -254,7 +257,6 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                         o = madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));          // o = o + 1e-4*d  (:549)
                         invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; ob = 0; sp = 0; cur = CUR_NONE;
-                        active = true;
                         for (int k = 0; k < nObjLds; k++) {
                             const ObjRoot R = sc.roots[k];
                             rootDist[k * TPB] = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
@@ -263,13 +265,12 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                 }
             }
             pos += (unsigned)nIdle;
-            nIdle = __popcll(__ballot(!active));
+            nIdle = __popcll(__ballot(cur == CUR_IDLE));
         }
         if (nIdle == 64) { if (pos >= end) break; continue; }
-        const bool wNext = active && cur == CUR_NONE;
         // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire
-        if (__any(wNext)) {
-            if (wNext) {
+        if (__any(cur == CUR_NONE)) {
+            if (cur == CUR_NONE) {
                 while (ob < sc.numObj) {
                     float rd;
                     if (ob < nObjLds) rd = rootDist[ob * TPB];
@@ -292,60 +293,71 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                         if (t < closest) { closest = t; prim = PRIM_ELLIPSOID | i; }
                     }
                     st.H[slot] = make_float4(closest, hu, hv, __int_as_float(prim));
-                    active = false;
+                    cur = CUR_IDLE;
                 }
             }
         }
-        const bool wInner = active && cur >= 0 && cur != CUR_NONE, wLeaf = active && cur < 0;
-        const int nInner = __popcll(__ballot(wInner)), nLeaf = __popcll(__ballot(wLeaf));
+        int nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
+        const int nLeaf = __popcll(__ballot(cur < 0));
         if (nInner >= nLeaf && nInner > 0) {
-            // ---- inner-node step (:521-532)
-            if (wInner) {
-                float4 q0, q1, q2, q3;
-                loadNode(sc, ldsN, cur, q0, q1, q2, q3);
-                if (COUNT) { c.nodes++; c.boxtests += 2; }
-                float Ld, Rd;
-                rayBox2(o, invD, q0, q1, q2, Ld, Rd);
-                int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
-                bool pl = Ld < closest, pr = Rd < closest;
-                if (COUNT) { if (pl && lref == REF_EMPTY) c.nodes++; if (pr && rref == REF_EMPTY) c.nodes++; }
-                pl = pl && lref != REF_EMPTY; pr = pr && rref != REF_EMPTY;
-                // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
-                bool rNear = Ld > Rd;
-                int nearRef = rNear ? rref : lref, farRef = rNear ? lref : rref;
-                bool nearOk = rNear ? pr : pl, farOk = rNear ? pl : pr;
-                if (nearOk) {
-                    cur = nearRef;
-                    if (farOk) { stk[sp * TPB] = (StackT)farRef; sp++; }
-                } else if (farOk) {
-                    cur = farRef;
-                } else if (sp > 0) {
-                    cur = (int)stk[(--sp) * TPB];
-                } else {
-                    cur = CUR_NONE;
+            // ---- inner-node steps (:521-532); repeated while most of the lanes that started the phase still sit on inner nodes
+            const int keepGoing = (nInner * keepEighths) >> 3;
+            do {
+                if ((unsigned)cur < (unsigned)CUR_NONE) {
+                    float4 q0, q1, q2, q3;
+                    loadNode(sc, ldsN, cur, q0, q1, q2, q3);
+                    if (COUNT) { c.nodes++; c.boxtests += 2; }
+                    float Ld, Rd;
+                    rayBox2(o, invD, q0, q1, q2, Ld, Rd);
+                    const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
+                    if (COUNT) { if (Ld < closest && lref == REF_EMPTY) c.nodes++; if (Rd < closest && rref == REF_EMPTY) c.nodes++; }
+                    // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
+                    const bool rNear = Ld > Rd;
+                    const int nearRef = rNear ? rref : lref, farRef = rNear ? lref : rref;
+                    const float nearD = rNear ? Rd : Ld, farD = rNear ? Ld : Rd;
+                    const bool nearOk = nearD < closest && nearRef != REF_EMPTY, farOk = farD < closest && farRef != REF_EMPTY;
+                    if (nearOk) {
+                        cur = nearRef;
+                        if (farOk) { stk[sp * TPB] = (StackT)farRef; sp++; }
+                    } else if (farOk) {
+                        cur = farRef;
+                    } else if (sp > 0) {
+                        cur = (int)stk[(--sp) * TPB];
+                    } else {
+                        cur = CUR_NONE;
+                    }
                 }
-            }
+                nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));
+            } while (nInner > keepGoing);
         } else if (nLeaf > 0) {
-            // ---- leaf step: one triangle of the pending leaf (:483-520)
-            if (wLeaf) {
-                int ti = -(cur + 1);
-                float4 t0, t1, t2;
-                loadTri(sc, ldsT, ti, t0, t1, t2);
-                unsigned idl = __float_as_uint(t2.y);
-                float t, u, v;
-                if (COUNT) c.tritests++;
-                rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
-                if (t > 0.0f && t < closest) {                              // :489
-                    closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
-                    if (COUNT) c.hitupd++;
+            // ---- leaf steps: one triangle of the pending leaf per step (:483-520); repeated while most lanes still have
+            // triangles left in their leaf (the reference's builder can leave many triangles in one leaf)
+            const int keepGoing = (nLeaf * keepEighths) >> 3;
+            int nMore;
+            do {
+                bool more = false;
+                if (cur < 0) {
+                    int ti = -(cur + 1);
+                    float4 t0, t1, t2;
+                    loadTri(sc, ldsT, ti, t0, t1, t2);
+                    unsigned idl = __float_as_uint(t2.y);
+                    float t, u, v;
+                    if (COUNT) c.tritests++;
+                    rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
+                    if (t > 0.0f && t < closest) {                          // :489
+                        closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
+                        if (COUNT) c.hitupd++;
+                    }
+                    if (idl >> 31) {                                        // last triangle of the leaf: this node is done
+                        if (COUNT) c.nodes++;
+                        cur = (sp > 0) ? (int)stk[(--sp) * TPB] : CUR_NONE;
+                    } else {
+                        cur = cur - 1;                                      // next triangle record of the same leaf
+                        more = true;
+                    }
                 }
-                if (idl >> 31) {                                            // last triangle of the leaf: this node is done
-                    if (COUNT) c.nodes++;
-                    cur = (sp > 0) ? (int)stk[(--sp) * TPB] : CUR_NONE;
-                } else {
-                    cur = cur - 1;                                          // next triangle record of the same leaf
-                }
-            }
+                nMore = __popcll(__ballot(more));
+            } while (nMore > keepGoing);
         }
     }
     if (COUNT) {
@@ -605,7 +617,7 @@ struct pt_ctx {
     int ldsBudget = 20 * 1024;
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
     int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
-    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 3;
+    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 3; int innerKeepEighths = 6;
     int compactBelowPct = 70;       // compact the queue when fewer than this % of the launched lanes are live
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
@@ -836,7 +848,7 @@ template <bool COUNT, typename StackT, int TPB>
 void launchEP(pt_ctx* c, const DevScene& sc, size_t lds, int grid, const unsigned* queue, int launched) {
     int nObjLds = std::min(sc.numObj, 8);
     hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, c->stream, sc, c->st, queue, c->dNQueue, launched, c->dCtl, c->refillMin,
-                       c->stackDepth, nObjLds);
+                       c->innerKeepEighths, nObjLds);
 }
 void launchExtendPersist(pt_ctx* c, const unsigned* queue, int launched) {
     DevScene sc = c->sc;
@@ -1151,6 +1163,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
         case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
+        case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");
 }

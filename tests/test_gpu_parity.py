@@ -243,3 +243,32 @@ def test_two_process_shards_on_one_gpu(pt):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
                           os.path.join(root, "tests", "_dist_gpu_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert "DIST_GPU_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_big_leaves_and_empty_leaf(pt, oracle, renderer_mod):
+    """hand-made BVH buffers: a leaf with many triangles (the reference's builder makes those, Q-11), and a node
+    with one null child, which the shader treats as a leaf without triangles (bitwise OR test, frag.glsl:478)"""
+    W, H = 64, 48
+    wl = pt.scenes.build("C2", W, H)
+    b = dict(wl.buffers)
+    tris = b[3].reshape(-1, 40)
+    n = len(tris)
+    lo = tris[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3).min(0); hi = tris[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3).max(0)
+    half = n // 2
+    def box(idx):
+        p = tris[idx][:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3)
+        return list(p.min(0)) + list(p.max(0))
+    # node 0: root (children 1, 2); node 1: leaf with `half` triangles; node 2: inner (children 3, -1 -> "leaf" without triangles per :478);
+    # node 3 would hold the rest but is unreachable through node 2 -> also list it under a second object root 4 (leaf)
+    data = np.zeros((5, 8), np.float32)
+    data[0, :6] = list(lo) + list(hi)
+    data[1, :6] = box(np.arange(half)); data[1, 6:] = [0, half]
+    data[2, :6] = box(np.arange(half, n))
+    data[3, :6] = box(np.arange(half, n)); data[3, 6:] = [half, n]
+    data[4, :6] = box(np.arange(half, n)); data[4, 6:] = [half, n]
+    tree = np.array([[0, 1, 2], [1, -1, -1], [2, 3, -1], [3, -1, -1], [4, -1, -1]], np.int32)
+    b[10] = data.reshape(-1); b[11] = tree.reshape(-1); b[12] = np.arange(n, dtype=np.int32); b[13] = np.array([2, 0, 4], np.int32)
+    wl2 = pt.scenes.Workload(wl.name, W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    for mode in (0, 1):
+        got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl2, 2, extend_mode=mode)
+        assert_same(got, ref, cnt, ocnt)
