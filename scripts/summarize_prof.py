@@ -43,7 +43,7 @@ def main(d):
                 a[0] += 1
                 a[1] += float(row["Counter_Value"])
     if agg:
-        print("\n## HBM traffic counters (separate --pmc passes: bench.py --steps 1 --warmup 0 --frames-per-step 1 --no-roofline)")
+        print("\n## HBM traffic counters (separate --pmc passes: bench.py --steps 1 --warmup 0 --frames-per-step 4 --no-roofline)")
         print("kernel,launches,FETCH_SIZE_KiB_per_launch(raw),WRITE_SIZE_KiB_per_launch,HBM_MB_per_launch(fetch x2 + write)")
         for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"][1] + kv[1]["WRITE_SIZE"][1])):
             if not k.startswith("k_"):
