@@ -272,3 +272,39 @@ def test_big_leaves_and_empty_leaf(pt, oracle, renderer_mod):
     for mode in (0, 1):
         got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl2, 2, extend_mode=mode)
         assert_same(got, ref, cnt, ocnt)
+
+
+@pytest.mark.parametrize("kw", [dict(SAMPLE_RES=1, MAX_BOUNCES=1), dict(SAMPLE_RES=3, MAX_BOUNCES=2.5), dict(AUTO_FOCUS=0, FOCAL_DISTANCE=2.5, BLUR=0.05),
+                                dict(BLUR=0.0), dict(screenSize=0.7, focalLength=1.3)])
+def test_parameter_block_variants(pt, oracle, renderer_mod, kw):
+    """Parameters block (frag.glsl:39-52): float loop bounds (:820,:898), auto-focus off, lens blur, field of view"""
+    wl = pt.scenes.build("C3", 100, 37).with_params(**kw)      # 100x37: not a multiple of the 32x8 tile
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
+    assert_same(got, ref, cnt, ocnt)
+
+
+def test_odd_size_sharded(pt, oracle, renderer_mod):
+    W, H = 100, 37
+    wl = pt.scenes.build("C2", W, H)
+    seeds = seeds_for(pt, 1, 2)
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, 2, seeds, nthreads=8)
+    acc = np.zeros_like(ref)
+    for rank in range(3):
+        rr = renderer_mod.Renderer(W, H, shard_rank=rank, shard_count=3)
+        rr.load_workload(wl); rr.reset_frame(); rr.render_batch(1, seeds)
+        rr.read_frame(acc); rr.close()
+    assert np.array_equal(acc, ref)
+
+
+def test_empty_scene_and_mouse_overlay(pt, oracle, renderer_mod):
+    """K2 on the device (no objects: every pixel = sky) and the mouse-probe region (frag.glsl:888-893) leaving FRAME untouched"""
+    W, H = 64, 48
+    sc = pt.hostlib.Scene(); sc.addMaterial("default")
+    b = sc.pack()
+    b[0] = np.zeros(3, np.float32); b[1] = np.array([0.1, 0.2, 0.0], np.float32); b[2] = np.array([20.0, 30.0, 0.0], np.float32)
+    b[4] = pt.scenes.make_params(W, H, 2, 4)
+    sky = np.array([[[10, 200, 90, 255], [250, 3, 77, 255]]], np.uint8)
+    wl = pt.scenes.Workload("empty", W, H, b, sky, 2, 4, {})
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
+    assert_same(got, ref)        # (the device also traces the overlay pixels and drops them at accumulation: counters differ by those)
+    assert np.all(got[30, 20] == 0) and np.all(got[0, 0, :3] > 0) and cnt["segments"] == cnt["samples"]
