@@ -46,12 +46,15 @@ constexpr int TILE_W = 32, TILE_H = 8;
 
 struct FrameIn { float params[12]; float origin[3]; float rotation[3]; float mouse[3]; };
 
-struct Control {            // device-resident scheduler words
+struct Control {            // device-resident scheduler words shared by the whole batch
     unsigned nextJob;       // next unassigned job
-    int nAlive;             // live path slots
-    unsigned nQueue;        // compaction output cursor
-    unsigned pad;
+    unsigned pad[3];
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
+};
+struct PoolCtl {            // per path pool (the batch runs as two half-pools on two streams, see renderBatch)
+    int nAlive;             // live path slots of this pool
+    unsigned nQueue;        // compaction output cursor
+    unsigned pad[30];       // one 128-B line per pool
 };
 
 struct State {              // SoA path pool, float4 groups (see header comment)
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
 // rays densely after a barrier.
 template <bool TRANS, bool STATS>
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
-                                                 int nSlots, Control* ctl) {
+                                                 int nSlots, Control* ctl, PoolCtl* pc) {
     __shared__ unsigned sPerm[BLOCK], sFlags[BLOCK];
     __shared__ uint4 sRegen[BLOCK];
     __shared__ unsigned sCntA[BLOCK / 64], sCntB[BLOCK / 64], sBase, sRegenCount;
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         else p.alive = false;
     }
     unsigned long long dead = __ballot(jobDone && !p.alive);
-    if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&ctl->nAlive, -(int)__popcll(dead));
+    if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&pc->nAlive, -(int)__popcll(dead));
     // ---- 5. store; lanes that start a sample do the prologue themselves and park the camera ray for the dense pass
     if (needStart) tracePrologue(p);
     unsigned long long ms = __ballot(needStart);
@@ -520,7 +523,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
 }
 
 // wave64 ballot + prefix-sum (mbcnt) stream compaction of live slot indices: one atomic per wave
-__global__ void __launch_bounds__(BLOCK) k_compact(State st, const unsigned* inQueue, const unsigned* nIn, int nSlots, unsigned* outQueue, Control* ctl) {
+__global__ void __launch_bounds__(BLOCK) k_compact(State st, const unsigned* inQueue, const unsigned* nIn, int nSlots, unsigned* outQueue, PoolCtl* pc) {
     unsigned n = inQueue ? *nIn : (unsigned)nSlots;
     unsigned q = blockIdx.x * BLOCK + threadIdx.x;
     bool valid = q < n;
@@ -531,7 +534,7 @@ __global__ void __launch_bounds__(BLOCK) k_compact(State st, const unsigned* inQ
     int lane = threadIdx.x & 63;
     int leader = __ffsll((long long)mask) - 1;
     unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&ctl->nQueue, (unsigned)__popcll(mask));
+    if (lane == leader) base = atomicAdd(&pc->nQueue, (unsigned)__popcll(mask));
     base = __shfl(base, leader);
     if (live) outQueue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
@@ -561,9 +564,12 @@ __global__ void k_unshard(const float4* gathered, const int* maps, int nSlots, i
     if (gp >= 0) full[gp] = gathered[k];
 }
 
-__global__ void k_init_control(Control* ctl, unsigned nextJob, int nAlive) { ctl->nextJob = nextJob; ctl->nAlive = nAlive; ctl->nQueue = 0; }
-__global__ void k_zero_queue_cursor(Control* ctl) { ctl->nQueue = 0; }
-__global__ void k_copy_queue_count(const Control* ctl, unsigned* nQueueOut) { *nQueueOut = ctl->nQueue; }
+__global__ void k_init_control(Control* ctl, unsigned nextJob, PoolCtl* pools, int alive0, int alive1) {
+    ctl->nextJob = nextJob;
+    pools[0].nAlive = alive0; pools[0].nQueue = 0; pools[1].nAlive = alive1; pools[1].nQueue = 0;
+}
+__global__ void k_zero_queue_cursor(PoolCtl* pc) { pc->nQueue = 0; }
+__global__ void k_copy_queue_count(const PoolCtl* pc, unsigned* nQueueOut) { *nQueueOut = pc->nQueue; }
 
 __global__ void k_debug_math(int fn, const float* x, const float* y, float* out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -609,8 +615,9 @@ struct pt_ctx {
     unsigned *dQueueA = nullptr, *dQueueB = nullptr, *dNQueue = nullptr;
     float4* dColbuf = nullptr; size_t colbufElems = 0;
     int* dSeeds = nullptr; int seedsCap = 0;
-    FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
-    int* hAlive = nullptr;          // pinned
+    FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr; PoolCtl* dPool = nullptr;
+    hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; std::vector<hipEvent_t> evRing; bool dualPool = false;
+    int* hAlive = nullptr;          // pinned, one int per pool
     FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr; int hSeedsCap = 0;   // pinned staging
     // options / stats
     bool countStats = false, timing = false;
@@ -836,21 +843,26 @@ int nextEventPair(pt_ctx::KT& k) {
     }
     return (int)k.used++;
 }
-#define TIMED_LAUNCH(kidx, ...)                                          \
-    do {                                                                 \
-        int ev_ = c->timing ? nextEventPair(c->kt[kidx]) : -1;          \
-        if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].first, s);      \
-        __VA_ARGS__;                                                     \
-        if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].second, s);     \
+#define TIMED_LAUNCH_ON(strm, kidx, ...)                                    \
+    do {                                                                   \
+        int ev_ = c->timing ? nextEventPair(c->kt[kidx]) : -1;            \
+        if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].first, strm);     \
+        __VA_ARGS__;                                                       \
+        if (ev_ >= 0) hipEventRecord(c->kt[kidx].ev[ev_].second, strm);    \
     } while (0)
+#define TIMED_LAUNCH(kidx, ...) TIMED_LAUNCH_ON(s, kidx, __VA_ARGS__)
 
+struct PoolRun {            // host view of one path pool while a batch runs
+    hipStream_t stream; State st; PoolCtl* pc; unsigned* dNQueue; unsigned *qCur, *qNext; const unsigned* queue; unsigned launched; int alive; int* hAlive;
+};
 template <bool COUNT, typename StackT, int TPB>
-void launchEP(pt_ctx* c, const DevScene& sc, size_t lds, int grid, const unsigned* queue, int launched) {
+void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int grid) {
     int nObjLds = std::min(sc.numObj, 8);
-    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, c->stream, sc, c->st, queue, c->dNQueue, launched, c->dCtl, c->refillMin,
+    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl, c->refillMin,
                        c->innerKeepEighths, nObjLds);
 }
-void launchExtendPersist(pt_ctx* c, const unsigned* queue, int launched) {
+void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
+    const int launched = (int)pr.launched;
     DevScene sc = c->sc;
     int tpb = c->extendTpb;
     // LDS per block: [node tile][triangle tile][root-box distances][traversal stacks]; the tile takes what the fixed parts leave
@@ -866,7 +878,7 @@ void launchExtendPersist(pt_ctx* c, const unsigned* queue, int launched) {
     int grid = c->numCUs * perCU;
     int maxUseful = (launched + tpb - 1) / tpb;                  // never more blocks than 1 lane per ray
     grid = std::max(1, std::min(grid, maxUseful));
-#define EP(COUNT, T, TPB) launchEP<COUNT, T, TPB>(c, sc, lds, grid, queue, launched)
+#define EP(COUNT, T, TPB) launchEP<COUNT, T, TPB>(c, pr, sc, lds, grid)
 #define EP_T(COUNT, T) do { if (tpb == 256) EP(COUNT, T, 256); else if (tpb == 512) EP(COUNT, T, 512); else EP(COUNT, T, 1024); } while (0)
     if (c->countStats) { if (c->stack16) EP_T(true, short); else EP_T(true, int); }
     else { if (c->stack16) EP_T(false, short); else EP_T(false, int); }
@@ -918,49 +930,90 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     } else { b.divM = 0; b.divS = 0; }
     int N = c->poolActive;
     unsigned first = (unsigned)std::min<size_t>((size_t)N, nJobs64);
-    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first, (int)first);
+    // Optional (pt_set_option 10, default off): two half-pools on two streams, so that the HBM-bound shading of one half
+    // runs underneath the VALU-bound intersection of the other; cross-stream events chain the intersect launches
+    // (E_A1 -> E_B1 -> E_A2 -> ...) so that two of them never share the machine.  Measured on C3: 812 vs 1210 Msamples/s —
+    // the shading kernel's HBM traffic stretches the intersect kernel's memory latency far more than the overlap gains
+    // (profiles/), so batches run as ONE pool on one stream.
+    const bool dual = c->dualPool && first >= (unsigned)(1 << 19);
+    const unsigned half = dual ? (unsigned)(((size_t)N / 2 + BLOCK - 1) / BLOCK * BLOCK) : (unsigned)N;
+    auto offsetState = [](State st, size_t off) {
+        State o = st;
+        o.G0 += off; o.G1 += off; o.G2 += off; o.G3 += off; o.G4 += off; o.H += off;
+        if (o.G5) { o.G5 += off; o.S0 += off; o.S1 += off; o.S2 += off; }
+        return o;
+    };
+    PoolRun pools[2];
+    const int nPools = dual ? 2 : 1;
+    for (int pi = 0; pi < nPools; pi++) {
+        PoolRun& pr = pools[pi];
+        size_t off = (size_t)pi * half;
+        pr.stream = pi ? c->sideStream : s;
+        pr.st = offsetState(c->st, off);
+        pr.pc = c->dPool + pi; pr.dNQueue = c->dNQueue + pi; pr.hAlive = c->hAlive + pi;
+        pr.qCur = c->dQueueA + off; pr.qNext = c->dQueueB + off; pr.queue = nullptr;
+        unsigned lo = (unsigned)std::min<size_t>(off, first), hi = (unsigned)std::min<size_t>(off + (pi == nPools - 1 ? (size_t)N : half), first);
+        pr.launched = hi - lo; pr.alive = (int)(hi - lo);
+    }
+    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first, c->dPool, pools[0].alive, dual ? pools[1].alive : 0);
     int gridN = (N + BLOCK - 1) / BLOCK;
     if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<true>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
     else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<false>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+    if (dual) { HIP_TRY(hipEventRecord(c->evFork, s)); HIP_TRY(hipStreamWaitEvent(c->sideStream, c->evFork, 0)); }
 
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
-    const unsigned* queue = nullptr;         // nullptr: identity (all slots)
-    unsigned launched = first;               // lanes worth launching (upper bound on live lanes)
-    unsigned* qCur = c->dQueueA; unsigned* qNext = c->dQueueB;
-    int alive = (int)first;
     uint64_t iters = 0;
     const int CHECK = 8;
     // every job retires within SAMPLE_RES * ceil(MAX_BOUNCES) iterations of being started, and a slot runs at most
     // ceil(jobs / slots) jobs back to back: a batch that exceeds this bound (x2) is a scheduler bug, not work
     const uint64_t maxIters = 2 * ((nJobs64 + first - 1) / first + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
-    while (alive > 0) {
+    hipEvent_t lastExtend = nullptr; hipStream_t lastExtendStream = nullptr;
+    size_t ring = 0;
+    auto anyAlive = [&]() { for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0) return true; return false; };
+    while (anyAlive()) {
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
         for (int k = 0; k < CHECK; k++) {
-            int grid = (int)((launched + BLOCK - 1) / BLOCK);
-            if (c->extendMode == 0) {
-                if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
-                else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, c->st, queue, c->dNQueue, (int)launched, c->dCtl));
-            } else {
-                TIMED_LAUNCH(0, launchExtendPersist(c, queue, (int)launched));
+            for (int pi = 0; pi < nPools; pi++) {
+                PoolRun& pr = pools[pi];
+                if (pr.alive <= 0) continue;
+                hipStream_t ps = pr.stream;
+                int grid = (int)((pr.launched + BLOCK - 1) / BLOCK);
+                if (dual && lastExtend && lastExtendStream != ps) HIP_TRY(hipStreamWaitEvent(ps, lastExtend, 0));
+                if (c->extendMode == 0) {
+                    if (c->countStats) TIMED_LAUNCH_ON(ps, 0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, ps, c->sc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl));
+                    else TIMED_LAUNCH_ON(ps, 0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, ps, c->sc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl));
+                } else {
+                    TIMED_LAUNCH_ON(ps, 0, launchExtendPersist(c, pr));
+                }
+                if (dual) {
+                    lastExtend = c->evRing[ring++ % c->evRing.size()]; lastExtendStream = ps;
+                    HIP_TRY(hipEventRecord(lastExtend, ps));
+                }
+#define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, ps, c->sc, b, c->dFc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl, pr.pc
+                if (c->trans) { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, true>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, false>), SHADE_ARGS)); }
+                else { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, true>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, false>), SHADE_ARGS)); }
             }
-#define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, s, c->sc, b, c->dFc, c->st, queue, c->dNQueue, (int)launched, c->dCtl
-            if (c->trans) { if (c->countStats) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<true, true>), SHADE_ARGS)); else TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<true, false>), SHADE_ARGS)); }
-            else { if (c->countStats) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<false, true>), SHADE_ARGS)); else TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<false, false>), SHADE_ARGS)); }
             iters++;
         }
-        HIP_TRY(hipMemcpyAsync(c->hAlive, &c->dCtl->nAlive, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        alive = *c->hAlive;
-        // tail: once job supply has run dry the pool thins out -> compact live slots into a dense queue
-        if (alive > 0 && (uint64_t)alive * 100 < (uint64_t)launched * (uint64_t)c->compactBelowPct) {
-            int grid = (int)((launched + BLOCK - 1) / BLOCK);
-            hipLaunchKernelGGL(k_zero_queue_cursor, dim3(1), dim3(1), 0, s, c->dCtl);
-            hipLaunchKernelGGL(k_compact, dim3(grid), dim3(BLOCK), 0, s, c->st, queue, c->dNQueue, (int)launched, qNext, c->dCtl);
-            hipLaunchKernelGGL(k_copy_queue_count, dim3(1), dim3(1), 0, s, c->dCtl, c->dNQueue);
-            queue = qNext; std::swap(qCur, qNext);
-            launched = (unsigned)alive;      // k_compact wrote exactly `alive` entries
+        for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0) HIP_TRY(hipMemcpyAsync(pools[pi].hAlive, &pools[pi].pc->nAlive, 4, hipMemcpyDeviceToHost, pools[pi].stream));
+        for (int pi = 0; pi < nPools; pi++) HIP_TRY(hipStreamSynchronize(pools[pi].stream));
+        lastExtend = nullptr;
+        for (int pi = 0; pi < nPools; pi++) {
+            PoolRun& pr = pools[pi];
+            if (pr.alive <= 0) continue;
+            pr.alive = *pr.hAlive;
+            // tail: once job supply has run dry the pool thins out -> compact live slots into a dense queue
+            if (pr.alive > 0 && (uint64_t)pr.alive * 100 < (uint64_t)pr.launched * (uint64_t)c->compactBelowPct) {
+                int grid = (int)((pr.launched + BLOCK - 1) / BLOCK);
+                hipLaunchKernelGGL(k_zero_queue_cursor, dim3(1), dim3(1), 0, pr.stream, pr.pc);
+                hipLaunchKernelGGL(k_compact, dim3(grid), dim3(BLOCK), 0, pr.stream, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, pr.qNext, pr.pc);
+                hipLaunchKernelGGL(k_copy_queue_count, dim3(1), dim3(1), 0, pr.stream, pr.pc, pr.dNQueue);
+                pr.queue = pr.qNext; std::swap(pr.qCur, pr.qNext);
+                pr.launched = (unsigned)pr.alive;      // k_compact wrote exactly `alive` entries
+            }
         }
     }
+    if (dual) { HIP_TRY(hipEventRecord(c->evJoin, c->sideStream)); HIP_TRY(hipStreamWaitEvent(s, c->evJoin, 0)); }
     int gridA = (c->nSlotsImg + BLOCK - 1) / BLOCK;
     TIMED_LAUNCH(3, hipLaunchKernelGGL(k_accumulate, dim3(gridA), dim3(BLOCK), 0, s, b, c->dFc, c->dFrame));
     HIP_TRY(hipGetLastError());
@@ -1021,8 +1074,15 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
     HIP_TRY(hipMalloc((void**)&c->dFc, sizeof(FrameConst)));
     HIP_TRY(hipMalloc((void**)&c->dCtl, sizeof(Control)));
     HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
-    HIP_TRY(hipMalloc((void**)&c->dNQueue, 4));
-    HIP_TRY(hipHostMalloc((void**)&c->hAlive, 4, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void**)&c->dNQueue, 8));
+    HIP_TRY(hipMalloc((void**)&c->dPool, 2 * sizeof(PoolCtl)));
+    HIP_TRY(hipMemset(c->dPool, 0, 2 * sizeof(PoolCtl)));
+    HIP_TRY(hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
+    c->evRing.resize(64);
+    for (auto& e : c->evRing) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&c->hAlive, 8, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->hFrameIn, sizeof(FrameIn), hipHostMallocDefault));
     c->imp = {0.0f}; c->ellip = {0.0f}; c->objidx = {0};
     c->mouse = {-1.0e6f, -1.0e6f, 0.0f};
@@ -1035,12 +1095,16 @@ int pt_destroy(pt_ctx* c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
-                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl};
+                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dPool};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hAlive) hipHostFree(c->hAlive);
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
     if (c->hSeeds) hipHostFree(c->hSeeds);
     for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (auto& e : c->evRing) hipEventDestroy(e);
+    if (c->evFork) hipEventDestroy(c->evFork);
+    if (c->evJoin) hipEventDestroy(c->evJoin);
+    if (c->sideStream) { hipStreamSynchronize(c->sideStream); hipStreamDestroy(c->sideStream); }
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return PT_OK;
@@ -1163,6 +1227,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
         case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
+        case 10: c->dualPool = value != 0; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");

@@ -233,6 +233,12 @@ def test_full_size_properties_c3(pt, oracle, renderer_mod):
     for i, s in enumerate(seeds):
         oracle.render(sc, W, H, 1 + i, s, ref, nthreads=8, xs=24, ys=27)
     assert np.array_equal(a[::27, ::24], ref[::27, ::24])
+    # the optional two-half-pools-on-two-streams schedule renders the same bits
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("dual_pool", 1)
+    r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds)
+    assert np.array_equal(r.read_frame(), a)
+    r.close()
 
 
 def test_two_process_shards_on_one_gpu(pt):
