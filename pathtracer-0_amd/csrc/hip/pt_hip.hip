@@ -963,15 +963,22 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
 
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
     uint64_t iters = 0;
-    const int CHECK = 8;
+    int CHECK = 8;
     // every job retires within SAMPLE_RES * ceil(MAX_BOUNCES) iterations of being started, and a slot runs at most
     // ceil(jobs / slots) jobs back to back: a batch that exceeds this bound (x2) is a scheduler bug, not work
     const uint64_t maxIters = 2 * ((nJobs64 + first - 1) / first + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
     hipEvent_t lastExtend = nullptr; hipStream_t lastExtendStream = nullptr;
     size_t ring = 0;
     auto anyAlive = [&]() { for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0) return true; return false; };
+    // Host polls of the live count drain the stream: while no slot has died yet the end is at least one whole job away
+    // (>= SAMPLE_RES iterations), so the steady state is polled every 24 iterations and only the tail every 8.
     while (anyAlive()) {
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
+        {
+            bool allFull = true;
+            for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0 && (unsigned)pools[pi].alive < pools[pi].launched) allFull = false;
+            CHECK = (allFull && nJobs64 > first) ? 24 : 8;
+        }
         for (int k = 0; k < CHECK; k++) {
             for (int pi = 0; pi < nPools; pi++) {
                 PoolRun& pr = pools[pi];
