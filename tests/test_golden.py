@@ -1,0 +1,74 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle): CPU = the oracle and the
+host-side scene packers still reproduce them bit for bit; GPU = the HIP path reproduces them without the oracle in the loop."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(glob.glob(os.path.join(HERE, "C*.npz")))
+
+
+def _load(path):
+    z = np.load(path)
+    name = os.path.basename(path).split("_")[0]
+    W, H = [int(v) for v in os.path.basename(path).split("_")[1].split("x")]
+    bufs = {int(k[1:]): z[k] for k in z.files if k.startswith("b")}
+    return name, W, H, z, bufs
+
+
+def _same(a, b):
+    return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def test_contract_vectors(oracle):
+    z = np.load(os.path.join(HERE, "contract.npz"))
+    for start, res, bits in zip(z["rng_start"], z["rng_result"], z["rng_random_bits"]):
+        _, r, rnd = oracle.rng(int(start), 8)
+        assert np.array_equal(r, res) and np.array_equal(rnd.view(np.uint32), bits)
+    x, u = z["x"], z["u"]
+    for fn, arg in (("sin", x), ("cos", x), ("exp", x * 10), ("log", u), ("asin", x / 7)):
+        assert _same(oracle.math(fn, arg), z[fn]), fn
+    assert _same(oracle.math("atan2", x, x[::-1].copy()), z["atan2"])
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
+def test_oracle_and_packers_reproduce_golden(pt, oracle, path):
+    name, W, H, z, bufs = _load(path)
+    kw = dict(subdiv=2) if name == "C5" else {}
+    wl = pt.scenes.build(name, W, H, **kw)
+    for k, v in bufs.items():                       # host-side scene producers: same bytes
+        assert np.array_equal(wl.buffers[k], v, equal_nan=True), f"binding {k}"
+    frame, cnt = oracle.render_frames(oracle.Scene(bufs, z["sky"]), W, H, 1, len(z["seeds"]), z["seeds"], nthreads=3)
+    assert _same(frame, z["frame"]) and np.array_equal(cnt, z["counters"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
+def test_hip_reproduces_golden(renderer_mod, path):
+    name, W, H, z, bufs = _load(path)
+    r = renderer_mod.Renderer(W, H)
+    for k, v in bufs.items():
+        r.set_buffer(k, v)
+    r.set_texture(0, z["sky"])
+    r.set_option("count_stats", 1)
+    r.reset_frame(); r.reset_counters()
+    r.render_batch(1, z["seeds"])
+    got = r.read_frame(); cnt = r.counters()
+    r.close()
+    assert _same(got, z["frame"])
+    ref = dict(zip(["segments", "nodes", "tritests", "hitupd", "samples", "boxtests"], [int(v) for v in z["counters"][:6]]))
+    for k, v in ref.items():
+        assert cnt[k] == v, (k, cnt[k], v)
+
+
+@pytest.mark.gpu
+def test_hip_contract_vectors(renderer_mod):
+    z = np.load(os.path.join(HERE, "contract.npz"))
+    r = renderer_mod.Renderer(32, 32)
+    x, u = z["x"], z["u"]
+    for fn, arg in (("sin", x), ("cos", x), ("exp", x * 10), ("log", u), ("asin", x / 7)):
+        assert _same(r.debug_math(fn, arg), z[fn]), fn
+    assert _same(r.debug_math("atan2", x, x[::-1].copy()), z["atan2"])
+    r.close()
