@@ -85,6 +85,12 @@ int pt_synchronize(pt_ctx* ctx);
  * host layer's single RCCL collective on pt_frame_device(). */
 int pt_read_frame(pt_ctx* ctx, float* rgba_out);
 
+/* The reference's screenshot path: display colour = FRAME.rgb / frame_count (frag.glsl:932) through an
+ * UNORM8 framebuffer (clamp, *255, round to nearest), glReadPixels(GL_RGB, GL_UNSIGNED_BYTE) (dispatch.java:813), the
+ * signed-byte packing of :819-822 when java_bytes != 0 (a channel >= 128 borrows 1 from the channel above it), vertical flip
+ * (:828-833).  rgb_out: width*height*3 bytes, top row first.  shard_count must be 1.  Synchronises. */
+int pt_read_display(pt_ctx* ctx, int frame_count, int java_bytes, uint8_t* rgb_out);
+
 /* Device-resident accumulator of this shard: n_pixels RGBA32F in shard-local pixel order
  * (shard_count == 1: plain row-major FRAME).  Valid until pt_destroy. */
 int pt_frame_device(pt_ctx* ctx, void** dev_ptr, size_t* n_pixels);

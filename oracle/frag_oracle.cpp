@@ -61,7 +61,7 @@ struct Mtl {
 };
 
 struct Hit {          // raySceneResult, frag.glsl:83-96 (only the members trace() consumes)
-    vec3 loc, norm; int material; int id; int type; float distance; vec3 dir; float uvx, uvy;
+    vec3 loc, norm; int material; int id; int type; float distance; vec3 dir; float uvx, uvy; int parentID;
 };
 
 struct Mat3 { float m[3][3]; };   // math (row-major) matrix
@@ -246,7 +246,7 @@ BvhResult rayBVH(Ctx& c, vec3 o, vec3 d, int top, float previous_closest_t) {
             for (int i = startIdx; i < endIdx; i++) {
                 int tri = s->leaf_tris[i];
                 const float* T = s->tris + 40 * (int64_t)tri;
-                float t, u, v;
+                float t = 0, u = 0, v = 0;
                 if (c.count) c.cnt[C_TRITESTS]++;
                 bool ok = rayTri(o, d, v3(T[0], T[1], T[2]), v3(T[4], T[5], T[6]), v3(T[8], T[9], T[10]), t, u, v);
                 float hx = ok ? t : 1e30f;
@@ -301,11 +301,11 @@ Hit rayScene(Ctx& c, vec3 o, vec3 d) {
     float closest_t = 1e30f;
     int hitType = 0, hitID = -1, hitMat = -1;
     float uvx = 0, uvy = 0;
-    float bu = 0, bv = 0; int btri = -1;
+    float bu = 0, bv = 0; int btri = -1; int parentID = -1;
     for (int I = 1; I < c.numObj + 1; I++) {
         int root = s->obj_indices[I];
         BvhResult r = rayBVH(c, o, d, root, closest_t);
-        if (r.any && r.t < closest_t) { closest_t = r.t; hitType = 1; hitID = r.id; btri = r.id; bu = r.u; bv = r.v; }
+        if (r.any && r.t < closest_t) { closest_t = r.t; hitType = 1; hitID = r.id; btri = r.id; bu = r.u; bv = r.v; parentID = root; }
     }
     if (btri >= 0) triShading(c, btri, bu, bv, N, uvx, uvy, hitMat);
     // implicits (frag.glsl:578-605): rayImplicit returns 1e30 unconditionally (:385-386); the
@@ -330,7 +330,7 @@ Hit rayScene(Ctx& c, vec3 o, vec3 d) {
         }
     }
     Hit h;
-    h.type = hitType; h.id = hitID; h.uvx = uvx; h.uvy = uvy;
+    h.type = hitType; h.id = hitID; h.uvx = uvx; h.uvy = uvy; h.parentID = parentID;
     if (closest_t < 1e25f) {
         h.loc = madd(d, closest_t, o); h.dir = normalize(d); h.norm = N; h.material = hitMat; h.distance = closest_t;
         return h;
@@ -470,6 +470,35 @@ vec3 trace(Ctx& c, Inv& g, vec3 o, vec3 d, uint32_t& rng) {
     return incLight;
 }
 
+// frag.glsl:655-681: the RAYTRACING == 0 mode.  One rayScene per sample; fixed up-light shading
+// col = Ka + 0.2 Kd + Kd * N.y + Ke (N is NOT flipped towards the ray); with subsurface > 0 the colour is replaced by
+// exp(-si / max(radius, 1e-4)) * subsurfaceColor where si = distance(o, rayBVH(hit.loc, d, hit.parentID, 1e30).loc):
+// that `.loc` is rayBVH's (t,u,v) triple, not a position (:493), the probe starts ON the surface without the 1e-4 offset
+// (rayBVH is called directly, :668), and an ellipsoid hit has parentID = -1 (out-of-bounds BVH read in the shader:
+// the restatement treats that probe as a miss, loc = 1e30).
+vec3 directDiffuse(Ctx& c, vec3 o, vec3 d) {
+    if (c.count) c.cnt[C_SEGMENTS]++;
+    Hit hit = rayScene(c, o, d);
+    if (hit.id > -1) {
+        Mtl m = newMtl(c, hit.material);
+        vec3 N = hit.norm;
+        vec3 col = m.Ka + m.Kd * 0.2f + (m.Kd * dot(v3(0.0f, 1.0f, 0.0f), N)) + m.Ke;
+        if (m.subsurface > 0.0f) {
+            vec3 loc = v3(1e30f);
+            if (hit.parentID >= 0) {
+                BvhResult r = rayBVH(c, hit.loc, d, hit.parentID, 1e30f);
+                if (r.any) loc = v3(r.t, r.u, r.v);
+            }
+            float si = distance(o, loc);
+            vec3 rad = v3(maxnum(m.subsurfaceRadius.x, 1e-4f), maxnum(m.subsurfaceRadius.y, 1e-4f), maxnum(m.subsurfaceRadius.z, 1e-4f));
+            vec3 sigma_t = v3(1.0f / rad.x, 1.0f / rad.y, 1.0f / rad.z);
+            col = exp3((-sigma_t) * si) * m.subsurfaceColor;
+        }
+        return col;
+    }
+    return bgCol(c, d);
+}
+
 // frag.glsl:884-934 for one pixel.  texCoord is the pixel centre (vert.glsl:14 interpolated).
 void shadePixel(Ctx& c, int px, int py, int W, int H, int u_frameCount, int u_seed, float mid_to_scene, float* FRAME) {
     float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
@@ -492,7 +521,8 @@ void shadePixel(Ctx& c, int px, int py, int W, int H, int u_frameCount, int u_se
         vec3 focal_point = c.ORIGIN + direction * internal_focal_distance;
         vec3 direction_adjusted = normalize(focal_point - origin_jittered);
         if (c.count) c.cnt[C_SAMPLES]++;
-        col = col + trace(c, g, origin_jittered, direction_adjusted, rng);
+        if (c.RAYTRACING == 1.0f) col = col + trace(c, g, origin_jittered, direction_adjusted, rng);
+        else col = col + directDiffuse(c, origin_jittered, direction_adjusted);          // :909-913
     }
     float inv = c.SAMPLE_RES;
     col = v3(col.x / inv, col.y / inv, col.z / inv);
@@ -515,7 +545,7 @@ int setupCtx(Ctx& c, const orc_scene* s) {
     c.numEllipsoids = (int)s->ellip[0];
     c.camRot = rotationMatrix(c.ROTATION);
     c.count = true;
-    if (c.RAYTRACING != 1.0f || c.DEBUG != 0.0f) return -2;     // directDiffuse / DEBUG: out of scope
+    if (c.DEBUG != 0.0f) return -2;                              // DEBUG traversal heat-map: out of scope
     if (c.numImplicits != 0) return -3;                          // implicits are dead code in the reference
     int nm = c.me > 0 ? (int)((s->n_mtl_floats - 1) / c.me) : 0;
     for (int m = 0; m < nm; m++) {
@@ -618,6 +648,35 @@ void orc_math(int fn, const float* x, const float* y, float* out, int64_t n) {
 void orc_rotate(const float* p, const float* rot, int back, float* out) {
     vec3 r = back ? rotateBack(v3(p[0], p[1], p[2]), v3(rot[0], rot[1], rot[2])) : rotate(v3(p[0], p[1], p[2]), v3(rot[0], rot[1], rot[2]));
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+// 8-bit display path = what the reference's screenshot writes:
+//   fragColor = newTotal / frameCount (frag.glsl:932; vec4(col,1) for frame 1, :927)  -> default framebuffer, UNORM8:
+//   clamp to [0,1], *255, round to nearest (NaN -> 0)  -> glReadPixels(GL_RGB, GL_UNSIGNED_BYTE) (dispatch.java:813)
+//   -> pixel = (r << 16) + (g << 8) + b with SIGNED Java bytes (:819-822): a channel >= 128 borrows 1 from the channel
+//      above it (Q-18, reproduced when java_bytes != 0)  -> vertical flip (:828-833) -> rows top first.
+// The Java2D bilinear AffineTransformOp used for the flip maps pixel centres onto pixel centres; its edge/alpha
+// behaviour is JRE-specific and not restated.
+void orc_display(const float* frame, int W, int H, int frameCount, int java_bytes, uint8_t* rgb_out) {
+    float fc = (float)frameCount;
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            const float* F = frame + 4 * ((int64_t)y * W + x);
+            int q[3];
+            for (int k = 0; k < 3; k++) {
+                float v = F[k] / fc;
+                v = (v != v) ? 0.0f : (v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v));
+                q[k] = (int)__builtin_floorf(v * 255.0f + 0.5f);
+            }
+            int r = q[0], g = q[1], b = q[2];
+            if (java_bytes) {
+                int32_t pix = (int32_t)((uint32_t)(int32_t)(int8_t)r << 16) + (int32_t)((uint32_t)(int32_t)(int8_t)g << 8) + (int32_t)(int8_t)b;
+                r = (pix >> 16) & 0xff; g = (pix >> 8) & 0xff; b = pix & 0xff;
+            }
+            uint8_t* o = rgb_out + 3 * ((int64_t)(H - 1 - y) * W + x);
+            o[0] = (uint8_t)r; o[1] = (uint8_t)g; o[2] = (uint8_t)b;
+        }
+    }
 }
 
 int orc_has_fma(void) { return __builtin_cpu_supports("fma") ? 1 : 0; }

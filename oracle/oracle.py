@@ -38,6 +38,7 @@ def lib():
         L.orc_rng.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_display.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         if not L.orc_has_fma():
             raise RuntimeError("oracle needs a CPU with FMA (built with -mfma)")
         _LIB = L
@@ -119,4 +120,13 @@ def autofocus(scene):
 def rotate(p, rot, back=False):
     p, rot, out = np.array(p, np.float32), np.array(rot, np.float32), np.zeros(3, np.float32)
     lib().orc_rotate(p.ctypes.data, rot.ctypes.data, 1 if back else 0, out.ctypes.data)
+    return out
+
+
+def display(frame, frame_count, java_bytes=True):
+    """8-bit screenshot image (H, W, 3) uint8, top row first, of a FRAME accumulator."""
+    H, W = frame.shape[:2]
+    f = np.ascontiguousarray(frame, dtype=np.float32)
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    lib().orc_display(f.ctypes.data, W, H, int(frame_count), 1 if java_bytes else 0, out.ctypes.data)
     return out

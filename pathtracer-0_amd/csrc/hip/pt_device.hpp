@@ -37,9 +37,10 @@ struct ObjRoot { float bmin[3]; float bmax[3]; int ref; int pad; };           //
 struct EllipRec {                                                                // frag.glsl:606-631
     float c[3], st[3], r; int mat; int rotated; float rot[3]; float R[9]; float RB[9]; float pad[2];
 };
-struct MatRec {                                                                  // the mtl fields trace()/chooseRay() read
-    float Kd[3], Ks[3], Ke[3], Tf[3]; float Tr, Ni, Density, Pm, Pr, Pc, Pcr, subsurface; int illum; int pad[3];
-};                                                                               // 24 dwords = 96 B
+struct MatRec {                                                                  // the mtl fields trace()/chooseRay()/directDiffuse() read
+    float Kd[3], Ks[3], Ke[3], Tf[3]; float Tr, Ni, Density, Pm, Pr, Pc, Pcr, subsurface; int illum;
+    float Ka[3], ssColor[3], ssRadius[3]; int pad[2];                            // only directDiffuse (frag.glsl:661-675)
+};                                                                               // 32 dwords = 128 B
 
 struct FrameConst {            // uniform per batch; written by k_frame_setup
     float screenSize, focalLength, resolution, screenHratio, SAMPLE_RES, MAX_BOUNCES, BLUR, FOCAL_DISTANCE, AUTO_FOCUS;
@@ -53,6 +54,7 @@ struct DevScene {
     const float4* nodes;  int nNodes;        // inner nodes
     const float4* tris;   int nTriRecs;      // leaf-ordered triangle records
     const float4* shade;  int nTris;         // by triangle id
+    const int* triObj;                       // by triangle id: index of the object (BVH) whose leaves hold it; -1 none, -2 several
     const ObjRoot* roots; int numObj;
     const EllipRec* ellip; int numEllip;
     const MatRec* mats;   int numMat;
@@ -165,12 +167,13 @@ PM_DEV void loadTri(const DevScene& sc, const float4* ldsT, int ti, float4& t0, 
 // only at push time; strict '<' on hits), so counters equal the oracle's.
 template <bool COUNT>
 PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int stride, const float4* ldsN, const float4* ldsT,
-                           float& outT, float& outU, float& outV, int& outPrim, Counters& cnt) {
-    vec3 o = madd(d, 1e-4f, oIn);                                  // o = o + 1e-4*d  (:549)
+                           float& outT, float& outU, float& outV, int& outPrim, Counters& cnt, bool probe = false, int probeObj = 0) {
+    vec3 o = probe ? oIn : madd(d, 1e-4f, oIn);                    // o = o + 1e-4*d  (:549); the thickness probe calls rayBVH directly (:668)
     vec3 invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float closest = 1e30f, hu = 0.0f, hv = 0.0f;
     int prim = PRIM_NONE;
-    for (int ob = 0; ob < sc.numObj; ob++) {
+    const int obFirst = probe ? probeObj : 0, obEnd = probe ? probeObj + 1 : sc.numObj;
+    for (int ob = obFirst; ob < obEnd; ob++) {
         const ObjRoot R = sc.roots[ob];
         if (COUNT) cnt.boxtests++;
         if (rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]) > closest) continue;   // :468
@@ -217,13 +220,16 @@ PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int s
             }
         }
     }
-    for (int i = 0; i < sc.numEllip; i++) {                         // :606-631
+    for (int i = 0; i < (probe ? 0 : sc.numEllip); i++) {           // :606-631
         const EllipRec& E = sc.ellip[i];
         vec3 c = v3(E.c[0], E.c[1], E.c[2]);
         float t;
         if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), c, E.r, E.st[0], E.st[1], E.st[2]);
         else t = rayEllipsoid(o, d, c, E.r, E.st[0], E.st[1], E.st[2]);
-        if (t < closest) { closest = t; prim = PRIM_ELLIPSOID | i; }
+        if (t < closest) {                                          // hit.parentID keeps the BVH of the last triangle hit (:573): park that
+            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) hu = __int_as_float(prim);   // triangle id in u (unused for ellipsoids)
+            closest = t; prim = PRIM_ELLIPSOID | i;
+        }
     }
     outT = closest; outU = hu; outV = hv; outPrim = prim;
 }
@@ -252,6 +258,9 @@ PM_DEV vec3 randLambertianDistVec(uint32_t& st) {
 // Path state of one lane (registers); stored SoA in groups of float4 (see pt_hip.hip)
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t FL_INOBJ = 1u << 20, FL_APPLYABS = 1u << 21, FL_ALIVE = 1u << 31;
+// directDiffuse's thickness probe (frag.glsl:668): the ray starts ON the hit point (no 1e-4 offset) and traverses only the BVH
+// of the object that was hit; the object index rides in bits 24-30
+constexpr uint32_t FL_PROBE = 1u << 22; constexpr int FL_PROBE_OBJ_SHIFT = 24; constexpr uint32_t FL_PROBE_OBJ_MASK = 0x7fu;
 
 struct Path {
     vec3 O, D;             // current ray
@@ -260,7 +269,7 @@ struct Path {
     uint32_t rng;
     uint32_t pix, fi, ls;  // job identity: global pixel (x | y<<16), frame slot of the batch, accumulator slot
     int bounce, sample, stackSize;
-    bool inObj, applyAbs, alive;
+    bool inObj, applyAbs, alive, probe; int probeObj;
     vec3 enter; float dist;   // RAY_ENTER_LOCATION, DISTANCE_TRAVELED
     float s[10];           // refractionIndiceStack
     bool g5loaded, g5dirty; // lazily fetched / modified (enter, dist) group, see k_shade
@@ -268,11 +277,12 @@ struct Path {
 
 PM_DEV uint32_t packFlags(const Path& p) {
     return (uint32_t)p.bounce | ((uint32_t)p.sample << 8) | ((uint32_t)p.stackSize << 16) | (p.inObj ? FL_INOBJ : 0u) |
-           (p.applyAbs ? FL_APPLYABS : 0u) | (p.alive ? FL_ALIVE : 0u);
+           (p.applyAbs ? FL_APPLYABS : 0u) | (p.alive ? FL_ALIVE : 0u) | (p.probe ? (FL_PROBE | ((uint32_t)p.probeObj << FL_PROBE_OBJ_SHIFT)) : 0u);
 }
 PM_DEV void unpackFlags(Path& p, uint32_t f) {
     p.bounce = f & 0xff; p.sample = (f >> 8) & 0xff; p.stackSize = (f >> 16) & 0xf;
     p.inObj = f & FL_INOBJ; p.applyAbs = f & FL_APPLYABS; p.alive = f & FL_ALIVE;
+    p.probe = f & FL_PROBE; p.probeObj = (int)((f >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK);
 }
 
 // index stack, frag.glsl:139-158, as a shift array with static indices (stale slots stay readable)
@@ -381,6 +391,7 @@ PM_DEV void tracePrologue(Path& p) {
     addToIndiceStack(p, 1.0029f);
     p.inObj = false;
     p.bounce = 0;
+    p.probe = false; p.probeObj = 0;
 }
 PM_DEV void startSample(const FrameConst& fc, int W, int H, int px, int py, Path& p) {
     cameraRay(fc, W, H, px, py, p.rng, p.O, p.D);
@@ -468,6 +479,62 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
         p.col = p.col * (w == 2 ? albedoKs : albedoKd);      // :873
     }
     return !((float)p.bounce < fc.MAX_BOUNCES);               // loop condition :820
+}
+
+// directDiffuse (frag.glsl:655-681), the RAYTRACING == 0 mode: ONE rayScene per sample, fixed up-light shading, and for
+// subsurface > 0 a thickness probe = a second launch of this lane's ray through the hit object's BVH only.  The sample's
+// radiance is left in p.inc; returns true when the sample is finished.  While a probe is in flight p.col carries
+// directDiffuse's `o` (the camera ray origin) and p.inc.x the material index (both groups are always written back).
+PM_DEV vec3 subsurfaceTint(const MatRec& m, vec3 o, vec3 loc) {
+    float si = distance(o, loc);                                                                          // :668
+    vec3 rad = v3(maxnum(m.ssRadius[0], 1e-4f), maxnum(m.ssRadius[1], 1e-4f), maxnum(m.ssRadius[2], 1e-4f));
+    vec3 sigma_t = v3(1.0f / rad.x, 1.0f / rad.y, 1.0f / rad.z);                                          // :671
+    return exp3((-sigma_t) * si) * v3(m.ssColor[0], m.ssColor[1], m.ssColor[2]);                          // :672
+}
+PM_DEV bool directSegment(const DevScene& sc, Path& p, float ht, float hu, float hv, int prim) {
+    if (p.probe) {                                            // second half of a subsurface sample: .loc of rayBVH is its (t,u,v) triple (:493)
+        const MatRec m = sc.mats[__float_as_int(p.inc.x)];
+        vec3 loc = (prim != PRIM_NONE) ? v3(ht, hu, hv) : v3(1e30f);
+        p.inc = subsurfaceTint(m, p.col, loc);
+        p.probe = false;
+        return true;
+    }
+    const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));
+    const vec3 D = p.D;
+    if (!hit) { p.inc = bgCol(sc, D); return true; }          // :679
+    vec3 o = madd(D, 1e-4f, p.O);
+    vec3 loc = madd(D, ht, o);
+    vec3 N; int mat;
+    const bool ellipsoid = (prim & PRIM_ELLIPSOID) != 0;
+    if (ellipsoid) {
+        const EllipRec& E = sc.ellip[prim & 0xffffff];
+        vec3 c = v3(E.c[0], E.c[1], E.c[2]);
+        if (E.rotated) N = normalize(vecmat(loc - c, E.RB)); else N = normalize(loc - c);
+        mat = E.mat;
+    } else {
+        const float4* S = sc.shade + 4 * (size_t)prim;
+        float4 s0 = S[0], s1 = S[1], s2 = S[2];
+        vec3 vn1 = v3(s0.x, s0.y, s0.z), vn2 = v3(s0.w, s1.x, s1.y);
+        if (vn1.x != 0.0f && vn1.y != 0.0f && vn1.z != 0.0f) N = normalize(vn2 * hu + vn2 * hv + vn1 * (1.0f - hu - hv));
+        else N = vn2;
+        mat = __float_as_int(s2.w);
+    }
+    const MatRec m = sc.mats[mat];
+    vec3 Kd = v3(m.Kd[0], m.Kd[1], m.Kd[2]);
+    vec3 col = v3(m.Ka[0], m.Ka[1], m.Ka[2]) + Kd * 0.2f + (Kd * dot(v3(0.0f, 1.0f, 0.0f), N)) + v3(m.Ke[0], m.Ke[1], m.Ke[2]);   // :661 (N not flipped)
+    if (m.subsurface > 0.0f) {
+        // hit.parentID (:573) is the BVH of the closest TRIANGLE found, also when an ellipsoid in front of it won (:619-630 do not reset it)
+        int triPrim = ellipsoid ? __float_as_int(hu) : prim;
+        int obj = (triPrim >= 0) ? sc.triObj[triPrim] : -1;
+        if (obj < 0) { p.inc = subsurfaceTint(m, p.O, v3(1e30f)); return true; }      // ellipsoid: parentID = -1, probe treated as a miss
+        p.col = p.O;                                          // directDiffuse's `o`
+        p.inc = v3(__int_as_float(mat), 0.0f, 0.0f);
+        p.O = loc;                                            // the probe starts on the hit point, same direction
+        p.probe = true; p.probeObj = obj;
+        return false;
+    }
+    p.inc = col;
+    return true;
 }
 
 }  // namespace ptd

@@ -191,7 +191,9 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
     float4 g0 = st.G0[i], g1 = st.G1[i];
     if (!(__float_as_uint(g1.w) & FL_ALIVE)) return;
     float t, u, v; int prim; Counters c;
-    intersectScene<COUNT>(sc, v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), stkBase + threadIdx.x, BLOCK, ldsN, ldsT, t, u, v, prim, c);
+    const unsigned fl = __float_as_uint(g1.w);
+    intersectScene<COUNT>(sc, v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), stkBase + threadIdx.x, BLOCK, ldsN, ldsT, t, u, v, prim, c,
+                          (fl & FL_PROBE) != 0, (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK));
     st.H[i] = make_float4(t, u, v, __int_as_float(prim));
     if (COUNT) {
         atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
@@ -242,7 +244,8 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     const unsigned end = min(pos + per, n);
     vec3 o = v3(0.0f), d = v3(0.0f), invD = v3(0.0f);
     float closest = 1e30f, hu = 0.0f, hv = 0.0f;
-    int prim = PRIM_NONE, ob = 0, sp = 0, cur = CUR_IDLE;
+    int prim = PRIM_NONE, ob = 0, obEnd = 0, sp = 0, cur = CUR_IDLE;
+    bool probe = false;
     unsigned slot = 0;
     Counters c;
     for (;;) {
@@ -255,11 +258,15 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                 if (q < end) {
                     slot = queue ? queue[q] : q;
                     float4 g0 = st.G0[slot], g1 = st.G1[slot];
-                    if (__float_as_uint(g1.w) & FL_ALIVE) {
+                    const unsigned fl = __float_as_uint(g1.w);
+                    if (fl & FL_ALIVE) {
                         d = v3(g0.w, g1.x, g1.y);
-                        o = madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));          // o = o + 1e-4*d  (:549)
+                        probe = (fl & FL_PROBE) != 0;                       // directDiffuse's thickness probe: rayBVH called directly (:668)
+                        o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
                         invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; ob = 0; sp = 0; cur = CUR_NONE;
+                        ob = probe ? (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK) : 0;
+                        obEnd = probe ? ob + 1 : sc.numObj;
+                        closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; sp = 0; cur = CUR_NONE;
                         for (int k = 0; k < nObjLds; k++) {
                             const ObjRoot R = sc.roots[k];
                             rootDist[k * TPB] = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
@@ -274,7 +281,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
         // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire
         if (__any(cur == CUR_NONE)) {
             if (cur == CUR_NONE) {
-                while (ob < sc.numObj) {
+                while (ob < obEnd) {
                     float rd;
                     if (ob < nObjLds) rd = rootDist[ob * TPB];
                     else { const ObjRoot R = sc.roots[ob]; rd = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); }
@@ -287,13 +294,16 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                     break;
                 }
                 if (cur == CUR_NONE) {                                      // all BVHs done: ellipsoids (:606-631), then retire the ray
-                    for (int i = 0; i < sc.numEllip; i++) {
+                    for (int i = 0; i < (probe ? 0 : sc.numEllip); i++) {
                         const EllipRec& E = sc.ellip[i];
                         vec3 cc = v3(E.c[0], E.c[1], E.c[2]);
                         float t;
                         if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
                         else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
-                        if (t < closest) { closest = t; prim = PRIM_ELLIPSOID | i; }
+                        if (t < closest) {
+                            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) hu = __int_as_float(prim);   // see intersectScene
+                            closest = t; prim = PRIM_ELLIPSOID | i;
+                        }
                     }
                     st.H[slot] = make_float4(closest, hu, hv, __int_as_float(prim));
                     cur = CUR_IDLE;
@@ -378,7 +388,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
 // run one stream each.  Camera rays (6 Gaussian draws + transforms, the heaviest piece) are not computed by the lane
 // that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes all parked
 // rays densely after a barrier.
-template <bool TRANS, bool STATS>
+template <bool TRANS, bool STATS, bool DIRECT>
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
                                                  int nSlots, Control* ctl, PoolCtl* pc) {
     __shared__ unsigned sPerm[BLOCK], sFlags[BLOCK];
@@ -421,7 +431,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
     // Groups are written back only when this segment changed them: sum (G4) at sample end; RAY_ENTER_LOCATION /
     // DISTANCE_TRAVELED (G5) when the transmission lobe won; index-stack slots 4-7 / 8-9 (S1/S2) are not even fetched
     // unless the stack is that deep (push/pop never touch slots above the current size, frag.glsl:142-158).
-    bool touchS1 = false, touchS2 = false, sampleDone = false, newJob = false;
+    bool touchS1 = false, touchS2 = false, sampleDone = false, newJob = false, isProbe = false;
     if (live) {
         // every load of the segment is issued here, in one batch (the flags came through LDS): the kernel's critical path
         // is memory round trips, not bytes
@@ -441,7 +451,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         p.sum = v3(g4.x, g4.y, g4.z); p.ls = __float_as_uint(g4.w);
         p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; p.g5dirty = false;
         p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
-        sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, i);
+        isProbe = DIRECT && p.probe;
+        if (DIRECT) sampleDone = directSegment(sc, p, h.x, h.y, h.z, __float_as_int(h.w));      // RAYTRACING == 0 (frag.glsl:911-912)
+        else sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, i);
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
             p.sample++;
@@ -502,12 +514,10 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         }
     }
     if (STATS) {                                  // statistics (count mode only): one atomic per wave
-        unsigned long long lm = __ballot(live);
+        unsigned long long lm = __ballot(live && !isProbe);      // a thickness probe is part of the same directDiffuse call
         unsigned long long sm = __ballot(nSamp != 0);
-        if (lm && lane == (__ffsll((long long)lm) - 1)) {
-            atomicAdd(&ctl->cnt[PT_CNT_SEGMENTS], (unsigned long long)__popcll(lm));
-            if (sm) atomicAdd(&ctl->cnt[PT_CNT_SAMPLES], (unsigned long long)__popcll(sm));
-        }
+        if (lm && lane == (__ffsll((long long)lm) - 1)) atomicAdd(&ctl->cnt[PT_CNT_SEGMENTS], (unsigned long long)__popcll(lm));
+        if (sm && lane == (__ffsll((long long)sm) - 1)) atomicAdd(&ctl->cnt[PT_CNT_SAMPLES], (unsigned long long)__popcll(sm));
     }
     __syncthreads();
     // ---- 6. dense camera-ray pass (frag.glsl:899-908): overwrites O, D, rngState of the parked slots
@@ -557,6 +567,28 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst*
     frame[ls] = F;
 }
 
+// fragColor -> UNORM8 framebuffer -> glReadPixels(GL_RGB) -> Java signed-byte packing -> vertical flip (dispatch.java:804-833)
+__global__ void __launch_bounds__(BLOCK) k_display(const float4* frame, int W, int H, float frameCount, int javaBytes, unsigned char* out) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= W * H) return;
+    int x = i % W, y = i / W;
+    float4 F = frame[i];
+    float v[3] = {F.x / frameCount, F.y / frameCount, F.z / frameCount};
+    int q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float t = (v[k] != v[k]) ? 0.0f : (v[k] < 0.0f ? 0.0f : (v[k] > 1.0f ? 1.0f : v[k]));
+        q[k] = (int)__builtin_floorf(t * 255.0f + 0.5f);
+    }
+    int r = q[0], g = q[1], b = q[2];
+    if (javaBytes) {
+        int pix = (int)((unsigned)(int)(signed char)r << 16) + (int)((unsigned)(int)(signed char)g << 8) + (int)(signed char)b;
+        r = (pix >> 16) & 0xff; g = (pix >> 8) & 0xff; b = pix & 0xff;
+    }
+    unsigned char* o = out + 3 * ((size_t)(H - 1 - y) * W + x);
+    o[0] = (unsigned char)r; o[1] = (unsigned char)g; o[2] = (unsigned char)b;
+}
+
 __global__ void k_unshard(const float4* gathered, const int* maps, int nSlots, int shardCount, float4* full) {
     size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= (size_t)nSlots * shardCount) return;
@@ -599,7 +631,7 @@ struct pt_ctx {
     std::vector<int32_t> bvhtree, leaftris, objidx;
     std::vector<uint8_t> sky; int skyW = 0, skyH = 0;
     bool sceneDirty = true, frameInDirty = true;
-    bool trans = false;
+    bool trans = false, anySubsurface = false, ambiguousTriObj = false; int* dTriObj = nullptr;
     int stackDepth = 1;
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
@@ -673,7 +705,7 @@ int buildScene(pt_ctx* c) {
     if (me < 48) return fail(PT_ERR_SCENE, "mtlData[0] (floats per material) must be >= 48");
     int nMat = (int)((c->mtl.size() - 1) / me);
     std::vector<MatRec> mats(std::max(nMat, 1));
-    c->trans = false;
+    c->trans = false; c->anySubsurface = false;
     for (int m = 0; m < nMat; m++) {
         const float* F = c->mtl.data() + (size_t)me * m;      // F[k] == mtlData[me*m + k]
         static const int maps[] = {22, 23, 24, 32, 33, 34, 35, 37, 38, 39, 40, 41};
@@ -681,14 +713,16 @@ int buildScene(pt_ctx* c) {
         MatRec& r = mats[m];
         for (int k = 0; k < 3; k++) { r.Kd[k] = F[4 + k]; r.Ks[k] = F[7 + k]; r.Tf[k] = F[13 + k]; r.Ke[k] = F[17 + k]; }
         r.Tr = F[12]; r.Ni = F[16]; r.Density = F[20]; r.illum = (int)F[21]; r.Pm = F[25]; r.Pr = F[26]; r.Pc = F[28]; r.Pcr = F[29]; r.subsurface = F[42];
-        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        for (int k = 0; k < 3; k++) { r.Ka[k] = F[1 + k]; r.ssColor[k] = F[43 + k]; r.ssRadius[k] = F[46 + k]; }
+        r.pad[0] = r.pad[1] = 0;
         if (r.Tr > 0.0f || r.Tf[0] > 0.0f || r.illum == 5 || r.illum == 7) c->trans = true;
+        if (r.subsurface > 0.0f) c->anySubsurface = true;
     }
     // objects / BVH
     int numObj = c->objidx[0];
     if (numObj < 0 || (size_t)numObj + 1 > c->objidx.size()) return fail(PT_ERR_SCENE, "objIndices[0] exceeds the buffer");
     auto childOf = [&](int n, int side) { return c->bvhtree[3 * (size_t)n + 1 + side]; };
-    std::vector<int> newIdx(nNodes, -1), depth(nNodes, 0);
+    std::vector<int> newIdx(nNodes, -1), depth(nNodes, 0), objOf(nNodes, -1);
     std::vector<int> order;                                     // inner nodes in multi-root BFS order
     std::vector<char> seen(nNodes, 0);
     std::vector<int> frontier;
@@ -697,7 +731,7 @@ int buildScene(pt_ctx* c) {
         int r = c->objidx[1 + o];
         if (r < 0 || (size_t)r >= nNodes) return fail(PT_ERR_SCENE, "objIndices root out of range");
         if (seen[r]) return fail(PT_ERR_SCENE, "BVH node reachable twice (not a tree)");
-        seen[r] = 1; frontier.push_back(r);
+        seen[r] = 1; frontier.push_back(r); objOf[r] = o;
     }
     int maxInnerDepth = -1;
     {
@@ -714,7 +748,7 @@ int buildScene(pt_ctx* c) {
                     int ch = childOf(n, s);
                     if (ch < 0 || (size_t)ch >= nNodes) return fail(PT_ERR_SCENE, "BVHtree child index out of range");
                     if (seen[ch]) return fail(PT_ERR_SCENE, "BVH node reachable twice (not a tree)");
-                    seen[ch] = 1; nxt.push_back(ch);
+                    seen[ch] = 1; nxt.push_back(ch); objOf[ch] = objOf[n];
                 }
             }
             cur.swap(nxt); d++;
@@ -725,6 +759,8 @@ int buildScene(pt_ctx* c) {
     c->stackDepth = std::max(need, 1);
     // leaf-ordered triangle records
     std::vector<float4> triRecs; std::vector<int> leafRef(nNodes, REF_EMPTY);
+    std::vector<int> triObj(std::max<size_t>(nTris, 1), -1);      // triangle -> object whose BVH holds it (hit.parentID of frag.glsl:573)
+    c->ambiguousTriObj = false;
     auto f4 = [](float a, float b, float cc, float d) { return make_float4(a, b, cc, d); };
     auto asf = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
     for (size_t n = 0; n < nNodes; n++) {
@@ -739,6 +775,7 @@ int buildScene(pt_ctx* c) {
             const float* T = c->tris.data() + 40 * (size_t)t;
             int mat = (int)T[36];
             if (mat < 0 || mat >= nMat) return fail(PT_ERR_SCENE, "triangle material index out of range (SURVEY.md Q-14: OBJ faces before any o/g line get -1)");
+            if (triObj[t] == -1) triObj[t] = objOf[n]; else if (triObj[t] != objOf[n]) { triObj[t] = -2; c->ambiguousTriObj = true; }
             float e1x = T[4] - T[0], e1y = T[5] - T[1], e1z = T[6] - T[2], e2x = T[8] - T[0], e2y = T[9] - T[1], e2z = T[10] - T[2];
             uint32_t idl = (uint32_t)t | (i == e - 1 ? 0x80000000u : 0u);
             triRecs.push_back(f4(T[0], T[1], T[2], e1x)); triRecs.push_back(f4(e1y, e1z, e2x, e2y)); triRecs.push_back(f4(e2z, asf(idl), 0, 0));
@@ -783,6 +820,7 @@ int buildScene(pt_ctx* c) {
     if ((rc = uploadVec((void**)&c->dNodes, nodeRecs.data(), nodeRecs.size() * 16, s))) return rc;
     if ((rc = uploadVec((void**)&c->dTris, triRecs.data(), triRecs.size() * 16, s))) return rc;
     if ((rc = uploadVec((void**)&c->dShade, shade.data(), shade.size() * 16, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dTriObj, triObj.data(), triObj.size() * 4, s))) return rc;
     if ((rc = uploadVec((void**)&c->dRoots, roots.data(), roots.size() * sizeof(ObjRoot), s))) return rc;
     if ((rc = uploadVec((void**)&c->dEllip, er.data(), er.size() * sizeof(EllipRec), s))) return rc;
     if ((rc = uploadVec((void**)&c->dMats, mats.data(), mats.size() * sizeof(MatRec), s))) return rc;
@@ -793,7 +831,7 @@ int buildScene(pt_ctx* c) {
     HIP_TRY(hipStreamSynchronize(s));
     DevScene& sc = c->sc;
     sc.nodes = c->dNodes; sc.nNodes = (int)order.size(); sc.tris = c->dTris; sc.nTriRecs = (int)(triRecs.size() / 3);
-    sc.shade = c->dShade; sc.nTris = (int)nTris; sc.roots = c->dRoots; sc.numObj = numObj; sc.ellip = c->dEllip; sc.numEllip = nE;
+    sc.shade = c->dShade; sc.nTris = (int)nTris; sc.triObj = c->dTriObj; sc.roots = c->dRoots; sc.numObj = numObj; sc.ellip = c->dEllip; sc.numEllip = nE;
     sc.mats = c->dMats; sc.numMat = nMat; sc.sky = c->dSky; sc.skyW = c->skyW; sc.skyH = c->skyH;
     // LDS tile: as many leading (top-of-tree) node records and triangle records as the budget allows
     int budget = c->ldsBudget - c->stackDepth * BLOCK * 4;
@@ -894,7 +932,11 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     if (c->sceneDirty && (rc = buildScene(c))) return rc;
     // parameter checks (scope: SURVEY.md §2)
     const float* P = c->params.data();
-    if (P[9] != 1.0f) return fail(PT_ERR_UNSUPPORTED, "RAYTRACING == 0 (directDiffuse, frag.glsl:655-681) is out of scope (SURVEY.md §8(f) N2)");
+    const bool direct = P[9] != 1.0f;                            // RAYTRACING == 0: directDiffuse (frag.glsl:655-681, :911-912)
+    if (direct && c->anySubsurface) {
+        if (c->sc.numObj > (int)FL_PROBE_OBJ_MASK) return fail(PT_ERR_UNSUPPORTED, "directDiffuse with subsurface materials supports at most 127 objects (BVHs)");
+        if (c->ambiguousTriObj) return fail(PT_ERR_SCENE, "directDiffuse with subsurface materials needs every triangle to belong to one BVH (hit.parentID, frag.glsl:573)");
+    }
     if (P[10] != 0.0f) return fail(PT_ERR_UNSUPPORTED, "DEBUG traversal heat-map (frag.glsl:539-547) is out of scope");
     if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
     if (!(P[4] >= 1.0f) || P[4] > 255.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,255]");
@@ -997,8 +1039,9 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
                     HIP_TRY(hipEventRecord(lastExtend, ps));
                 }
 #define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, ps, c->sc, b, c->dFc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl, pr.pc
-                if (c->trans) { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, true>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, false>), SHADE_ARGS)); }
-                else { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, true>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, false>), SHADE_ARGS)); }
+                if (direct) { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, true, true>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, false, true>), SHADE_ARGS)); }
+                else if (c->trans) { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, true, false>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, false, false>), SHADE_ARGS)); }
+                else { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, true, false>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, false, false>), SHADE_ARGS)); }
             }
             iters++;
         }
@@ -1101,7 +1144,7 @@ int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
+    void* ptrs[] = {c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dPool};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hAlive) hipHostFree(c->hAlive);
@@ -1174,6 +1217,21 @@ int pt_read_frame(pt_ctx* c, float* out) {
     HIP_TRY(hipMemcpyAsync(tmp.data(), c->dFrame, tmp.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->nLocal; k++) std::memcpy(out + 4 * (size_t)c->pixList[k], tmp.data() + 4 * (size_t)k, 16);
+    return PT_OK;
+}
+
+int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out) {
+    if (!c || !rgb_out) return fail(PT_ERR_ARG, "pt_read_display: null argument");
+    if (c->shardCount != 1) return fail(PT_ERR_ARG, "pt_read_display needs the whole image: gather the shards first (shard_count must be 1)");
+    HIP_TRY(hipSetDevice(c->device));
+    size_t bytes = (size_t)c->W * c->H * 3;
+    unsigned char* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    hipLaunchKernelGGL(k_display, dim3((unsigned)(((size_t)c->W * c->H + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->dFrame, c->W, c->H, (float)frame_count, java_bytes, d);
+    hipError_t e = hipMemcpyAsync(rgb_out, d, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("pt_read_display: ") + hipGetErrorString(e));
     return PT_OK;
 }
 

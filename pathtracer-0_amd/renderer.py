@@ -39,6 +39,7 @@ def lib():
         L.pt_render_batch.argtypes = [vp, ci, ci, vp]
         L.pt_synchronize.argtypes = [vp]
         L.pt_read_frame.argtypes = [vp, vp]
+        L.pt_read_display.argtypes = [vp, ci, ci, vp]
         L.pt_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
         L.pt_shard_slots.argtypes = [ci, ci, ci, C.POINTER(sz)]
         L.pt_shard_map.argtypes = [ci, ci, ci, ci, vp, sz]
@@ -136,6 +137,16 @@ class Renderer:
         assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == self.W * self.H * 4
         _check(self._L.pt_read_frame(self._h, out.ctypes.data))
         return out
+
+    def read_display(self, frame_count, java_bytes=True):
+        """The reference's screenshot image: (H, W, 3) uint8, top row first (functions.screenshot, dispatch.java:804-851)."""
+        out = np.zeros((self.H, self.W, 3), dtype=np.uint8)
+        _check(self._L.pt_read_display(self._h, int(frame_count), 1 if java_bytes else 0, out.ctypes.data))
+        return out
+
+    def screenshot(self, path, frame_count, java_bytes=True):
+        from PIL import Image
+        Image.fromarray(self.read_display(frame_count, java_bytes)).save(path)
 
     def frame_device(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -160,7 +160,7 @@ def test_errors_surface(pt, renderer_mod):
     wl = pt.scenes.build("C2", 64, 36)
     r = renderer_mod.Renderer(64, 36)
     r.load_workload(wl)
-    bad = wl.buffers[4].copy(); bad[9] = 0.0
+    bad = wl.buffers[4].copy(); bad[10] = 1.0                 # DEBUG heat-map: out of scope
     r.set_buffer(4, bad)
     with pytest.raises(renderer_mod.PtError) as e:
         r.render(1, 1)
@@ -314,3 +314,35 @@ def test_empty_scene_and_mouse_overlay(pt, oracle, renderer_mod):
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
     assert_same(got, ref)        # (the device also traces the overlay pixels and drops them at accumulation: counters differ by those)
     assert np.all(got[30, 20] == 0) and np.all(got[0, 0, :3] > 0) and cnt["segments"] == cnt["samples"]
+
+
+def test_n4_display_path(pt, oracle, renderer_mod):
+    """8-bit screenshot path on the device == the oracle's, with and without the Java signed-byte packing"""
+    W, H = 96, 54
+    wl = pt.scenes.build("C3", W, H)
+    seeds = seeds_for(pt, 1, 3)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds)
+    frame = r.read_frame()
+    for jb in (False, True):
+        got = r.read_display(3, java_bytes=jb)
+        assert np.array_equal(got, oracle.display(frame, 3, java_bytes=jb))
+    r.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name", ["C3", "C5", "C1"])
+def test_n2_direct_diffuse_mode(pt, oracle, renderer_mod, name, mode):
+    """RAYTRACING == 0 (directDiffuse, frag.glsl:655-681): one segment per sample, the thickness probe for
+    subsurface materials (C5), and an ellipsoid with a subsurface material (parentID = -1: probe treated as a miss)"""
+    kw = dict(subdiv=2) if name == "C5" else {}
+    wl = pt.scenes.build(name, 96, 54, **kw).with_params(RAYTRACING=0)
+    if name == "C1":
+        b = dict(wl.buffers); m = b[14].copy()
+        m[1 + 48 + 42 - 1 + 0] = 0.5                      # material 1: subsurface
+        m[1 + 48 + 43 - 1: 1 + 48 + 46 - 1] = [0.4, 0.8, 0.5]; m[1 + 48 + 46 - 1: 1 + 48 + 49 - 1] = [1, 1, 1]
+        b[14] = m
+        wl = pt.scenes.Workload(wl.name, wl.W, wl.H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, extend_mode=mode)
+    assert_same(got, ref, cnt, ocnt)
+    assert cnt["segments"] == cnt["samples"]

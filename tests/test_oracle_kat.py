@@ -214,7 +214,7 @@ def test_q6_ellipsoid_from_inside_returns_negative_root(pt, oracle):
 def test_oracle_rejects_out_of_scope_modes(pt, oracle):
     W, H = 8, 6
     b, sky = _scene(pt, W, H, mats=[{}])
-    b[4][9] = 0.0                              # RAYTRACING == 0
+    b[4][10] = 1.0                             # DEBUG heat-map
     with pytest.raises(RuntimeError):
         _render(oracle, b, sky, W, H)
 
@@ -227,3 +227,39 @@ def test_oracle_threads_and_strides_agree(pt, oracle):
     assert np.array_equal(a, b) and np.array_equal(ca, cb)
     c, _ = oracle.render(sc, 48, 27, 1, 77, xs=4, ys=3, nthreads=2)
     assert np.array_equal(c[::3, ::4], a[::3, ::4]) and np.all(c[1::3] == 0)
+
+
+def test_n4_display_path_and_java_signed_byte_quirk(oracle):
+    """screenshot path (dispatch.java:804-833): total/frameCount -> UNORM8 -> (r<<16)+(g<<8)+b with signed Java bytes -> flip"""
+    fr = np.zeros((2, 3, 4), np.float32)
+    fr[0, 0] = [1.2, 0.6, 0.3, 2]      # /2 -> 0.6, 0.3, 0.15 -> 153, 77 (76.5 rounds up), 38
+    fr[0, 1] = [2.0, 2.0, 2.0, 2]      # -> 255,255,255
+    fr[1, 2] = [-1.0, np.nan, 9.0, 2]  # clamp: 0, NaN -> 0, 255
+    d = oracle.display(fr, 2, java_bytes=False)
+    assert d.shape == (2, 3, 3)
+    assert d[1, 0].tolist() == [153, 77, 38] and d[1, 1].tolist() == [255, 255, 255] and d[0, 2].tolist() == [0, 0, 255]   # row 0 of FRAME is the bottom row
+    j = oracle.display(fr, 2, java_bytes=True)
+
+    def java(r, g, b):          # int arithmetic of dispatch.java:819-822 with signed bytes
+        sb = lambda v: v - 256 if v >= 128 else v
+        pix = ((sb(r) << 16) + (sb(g) << 8) + sb(b)) & 0xFFFFFFFF
+        return [(pix >> 16) & 255, (pix >> 8) & 255, pix & 255]
+    assert j[1, 0].tolist() == java(153, 77, 38) == [153, 77, 38]
+    assert j[1, 1].tolist() == java(255, 255, 255) == [254, 254, 255]      # each channel >= 128 borrows from the one above
+    assert j[0, 2].tolist() == java(0, 0, 255) == [255, 255, 255]          # blue >= 128 borrows through green into red
+
+
+def test_n2_direct_diffuse_known_answers(pt, oracle):
+    """directDiffuse (frag.glsl:661): col = Ka + 0.2 Kd + Kd * N.y + Ke with the UNFLIPPED normal; bgCol on a miss"""
+    W, H = 8, 6
+    kd, ke = (0.5, 0.25, 0.75), (0.1, 0.2, 0.3)
+    for n, ny in (("0 0 -1", 0.0), ("0 1 0", 1.0), ("0 -1 0", -1.0)):
+        b, sky = _scene(pt, W, H, BIG_TRI.format(z=5, z2=500, n=n), mats=[dict(Kd=kd, Ke=ke, Pr=1)], sky=(255, 255, 255))
+        b[4][9] = 0.0
+        fr = _render(oracle, b, sky, W, H)
+        exp = np.float32(0.2) * np.array(kd, np.float32) + np.array(kd, np.float32) * np.float32(ny) + np.array(ke, np.float32)
+        assert np.allclose(fr[..., :3], exp, rtol=1e-6, atol=1e-7), n
+    b, sky = _scene(pt, W, H, mats=[{}], sky=(51, 102, 204))
+    b[4][9] = 0.0
+    fr = _render(oracle, b, sky, W, H)
+    assert np.allclose(fr[..., :3], np.array([51, 102, 204], np.float32) / 255, rtol=3e-7)
