@@ -31,7 +31,7 @@ enum {
     PT_ERR_SCENE = -4,      /* scene buffers inconsistent (index out of range, BVH deeper than the
                                reference's int stack[64] (frag.glsl:465), ...) */
     PT_ERR_UNSUPPORTED = -5 /* feature the reference has but SURVEY.md §2/§8(f) scopes out
-                               (RAYTRACING==0, DEBUG, implicits, material texture maps) */
+                               (DEBUG, implicits, texture-mapped materials on ellipsoids) */
 };
 
 /* SSBO binding points of frag.glsl:14-77 accepted by pt_set_buffer */
@@ -60,8 +60,9 @@ const char* pt_last_error(void);
 
 /* glBufferData / glBufferSubData on the SSBO bound at `binding` (copy at call time). */
 int pt_set_buffer(pt_ctx* ctx, int binding, const void* data, size_t bytes);
-/* Texture upload + bindless handle slot `index` (dispatch.java:334-378): RGBA8, LINEAR, REPEAT.
- * Only index 0 (the sky, frag.glsl:235-242) is read on the hot path. */
+/* Texture upload + bindless handle slot `index` (dispatch.java:334-378): RGBA8, LINEAR, REPEAT, row 0 first as stbi_load
+ * delivers it.  Index 0 is the sky (frag.glsl:235-242); the others are what materials' map_* fields name (mapMtl,
+ * frag.glsl:210-225, and the raw-texel normal of :827). */
 int pt_set_texture(pt_ctx* ctx, int index, int width, int height, const uint8_t* rgba8);
 
 /* resetTexture(FRAME)                                             dispatch.java:732-735 */

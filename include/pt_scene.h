@@ -31,10 +31,28 @@ int pts_add_material(pts_scene* s, const char* name);
  * ("Not a valid property"), wrong arity -> error (IllegalArgumentException in Java). */
 int pts_set_last_mtl(pts_scene* s, const char* property, const double* val, int n);
 
+/* textures.add(path); textureNames.add(name)                       dispatch.java:221-222 (the sky is entry 0), :1570-1571
+ * -> index of the new entry in the texture table (binding 15).  The host layer decodes the files (the reference: stbi_load,
+ * dispatch.java:343) and hands the pixels to pt_set_texture(index, ...). */
+int pts_add_texture(pts_scene* s, const char* path, const char* name);
+int pts_texture_count(pts_scene* s);
+const char* pts_texture_path(pts_scene* s, int index);
+const char* pts_texture_name(pts_scene* s, int index);
+
+/* material.parseMtls(filePath, parentDirectoryPath)                dispatch.java:1319-1512
+ * One material per `newmtl` block (a block ends at the first empty line), named <name><parentDirectoryPath>; keys Ka Kd Ks Ns
+ * d (sets Tr = 1-d) Tr (sets d = 1-Tr) Tf Ni Ke (sets Density = |Ke|) Density illum Pm Pr Ps Pc Pcr aniso anisor subsurface
+ * subsurfaceColor subsurfaceRadius and the maps map_Ka map_Kd map_Ks map_Pm map_Pr|refl map_Ps map_Pc map_Pcr
+ * map_Bump|bump|map_bump map_d map_Tr map_Ns map_Ke, each registering <parentDirectoryPath>/<file> in the texture table unless
+ * a texture of that name is already there.  Lines are split on single spaces, as the Java does. */
+int pts_parse_mtls(pts_scene* s, const char* mtl_path, const char* parent_directory);
+
 /* scene.addObject(filepath, material, scale, shift, rot) for a regular .obj file
  *                                                                  dispatch.java:867-886, 888-1003
  * parent_directory may be NULL (then "usemtl X" looks for a material named "Xnull", exactly
- * as the Java string concatenation does, :924). One BVH per o/g group (:907-921, :993-997). */
+ * as the Java string concatenation does, :924). One BVH per o/g group (:907-921, :993-997).
+ * When obj_path is a DIRECTORY (:869-882): every *.mtl in it goes through pts_parse_mtls(file, dir) and every *.obj through the
+ * OBJ parser with parentDirectory = dir (files in alphabetical order; Java's listFiles order is unspecified). */
 int pts_add_object(pts_scene* s, const char* obj_path, int material, const double scale[3],
                    const double shift[3], const double rot[3], const char* parent_directory);
 /* same parser fed from memory (procedural meshes) */

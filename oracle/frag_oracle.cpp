@@ -44,6 +44,11 @@ struct orc_scene {
     int64_t n_mtl_floats;
     const uint8_t* sky;         // texture 0, RGBA8, row 0 first
     int32_t sky_w, sky_h;
+    // binding 15: the bindless texture table (dispatch.java:334-378); entry 0 = sky.  RGBA8, row 0 first; NULL = not uploaded
+    const uint8_t* const* tex;
+    const int32_t* tex_w;
+    const int32_t* tex_h;
+    int32_t n_tex;
 };
 
 // counters: S, Nv, Tt, Hu + extras
@@ -123,8 +128,7 @@ Mtl newMtl(const Ctx& c, int m) {
 
 // ---- texture(): GL 4.6 §8.14, LINEAR min/mag, REPEAT wrap, RGBA8 UNORM (dispatch.java:349-354) ----
 int imod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
-vec3 sampleSky(const Ctx& c, float u, float v) {
-    int w = c.s->sky_w, h = c.s->sky_h; const uint8_t* px = c.s->sky;
+vec3 sampleTex(const uint8_t* px, int w, int h, float u, float v) {
     float fu = u * (float)w - 0.5f, fv = v * (float)h - 0.5f;
     float flu = (__builtin_fabsf(fu) < 1.0e9f) ? __builtin_floorf(fu) : 0.0f;
     float flv = (__builtin_fabsf(fv) < 1.0e9f) ? __builtin_floorf(fv) : 0.0f;
@@ -139,6 +143,29 @@ vec3 sampleSky(const Ctx& c, float u, float v) {
         out[k] = w00 * t00 + w10 * t10 + w01 * t01 + w11 * t11;
     }
     return v3(out[0], out[1], out[2]);
+}
+vec3 sampleSky(const Ctx& c, float u, float v) { return sampleTex(c.s->sky, c.s->sky_w, c.s->sky_h, u, v); }
+// sampleTexture(), frag.glsl:79-81
+vec3 sampleTexture(const Ctx& c, int index, float u, float v) {
+    const orc_scene* s = c.s;
+    if (index == 0 || !s->tex) return sampleSky(c, u, v);
+    return sampleTex(s->tex[index], s->tex_w[index], s->tex_h[index], u, v);
+}
+// mapMtl(), frag.glsl:210-225: mapped materials are reset to mapped values, otherwise unchanged
+Mtl mapMtl(const Ctx& c, const Mtl& M, float u, float v) {
+    Mtl m = M;
+    if (M.map_Ka > -1) m.Ka = sampleTexture(c, M.map_Ka, u, v) * M.Ka;
+    if (M.map_Kd > -1) m.Kd = sampleTexture(c, M.map_Kd, u, v) * M.Kd;
+    if (M.map_Ks > -1) m.Ks = sampleTexture(c, M.map_Ks, u, v);
+    if (M.map_Ke > -1) m.Ke = sampleTexture(c, M.map_Ke, u, v);
+    if (M.map_d > -1) m.d = sampleTexture(c, M.map_d, u, v).x;
+    if (M.map_Tr > -1) m.Tr = sampleTexture(c, M.map_Tr, u, v).x;
+    if (M.map_Ns > -1) m.Ns = sampleTexture(c, M.map_Ns, u, v).x;
+    if (M.map_Pm > -1) m.Pm = sampleTexture(c, M.map_Pm, u, v).x;
+    if (M.map_Pr > -1) m.Pr = sampleTexture(c, M.map_Pr, u, v).x;
+    if (M.map_Ps > -1) m.Ps = sampleTexture(c, M.map_Ps, u, v).x;
+    if (M.map_Pc > -1) m.Pc = sampleTexture(c, M.map_Pc, u, v).x;
+    return m;
 }
 // frag.glsl:235-242
 vec3 bgCol(const Ctx& c, vec3 In) {
@@ -425,8 +452,8 @@ vec3 trace(Ctx& c, Inv& g, vec3 o, vec3 d, uint32_t& rng) {
         Hit hit = rayScene(c, O, D);
         if (hit.id > -1) {
             O = hit.loc;
-            Mtl m = newMtl(c, hit.material);          // mapMtl: no map_* > -1 (validated up front)
-            vec3 N = hit.norm;
+            Mtl m = mapMtl(c, newMtl(c, hit.material), hit.uvx, hit.uvy);                       // :825-826
+            vec3 N = (m.map_norm > -1) ? sampleTexture(c, m.map_norm, hit.uvx, hit.uvy) : hit.norm;   // :827 raw texel, no tangent frame
             vec3 emission = m.Ke;
             float ND = dot(N, D);
             N = N * (ND > 0.0f ? -1.0f : 1.0f);
@@ -480,8 +507,8 @@ vec3 directDiffuse(Ctx& c, vec3 o, vec3 d) {
     if (c.count) c.cnt[C_SEGMENTS]++;
     Hit hit = rayScene(c, o, d);
     if (hit.id > -1) {
-        Mtl m = newMtl(c, hit.material);
-        vec3 N = hit.norm;
+        Mtl m = mapMtl(c, newMtl(c, hit.material), hit.uvx, hit.uvy);                           // :658-659
+        vec3 N = (m.map_norm > -1) ? sampleTexture(c, m.map_norm, hit.uvx, hit.uvy) : hit.norm;       // :660
         vec3 col = m.Ka + m.Kd * 0.2f + (m.Kd * dot(v3(0.0f, 1.0f, 0.0f), N)) + m.Ke;
         if (m.subsurface > 0.0f) {
             vec3 loc = v3(1e30f);
@@ -548,11 +575,14 @@ int setupCtx(Ctx& c, const orc_scene* s) {
     if (c.DEBUG != 0.0f) return -2;                              // DEBUG traversal heat-map: out of scope
     if (c.numImplicits != 0) return -3;                          // implicits are dead code in the reference
     int nm = c.me > 0 ? (int)((s->n_mtl_floats - 1) / c.me) : 0;
-    for (int m = 0; m < nm; m++) {
+    for (int m = 0; m < nm; m++) {                               // every texture a material names must have been uploaded
         Mtl t = newMtl(c, m);
-        if (t.map_Ka > -1 || t.map_Kd > -1 || t.map_Ks > -1 || t.map_Ke > -1 || t.map_d > -1 || t.map_Tr > -1 || t.map_Ns > -1 ||
-            t.map_Pm > -1 || t.map_Pr > -1 || t.map_Ps > -1 || t.map_Pc > -1 || t.map_norm > -1)
-            return -4;                                           // material texture maps: SURVEY §8(f) N3
+        const int maps[] = {t.map_Ka, t.map_Kd, t.map_Ks, t.map_Ke, t.map_d, t.map_Tr, t.map_Ns, t.map_Pm, t.map_Pr, t.map_Ps, t.map_Pc, t.map_norm};
+        for (int idx : maps) {
+            if (idx <= -1) continue;
+            if (idx == 0) continue;
+            if (!s->tex || idx >= s->n_tex || !s->tex[idx]) return -4;
+        }
     }
     return 0;
 }

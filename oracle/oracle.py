@@ -17,7 +17,8 @@ class _Scene(C.Structure):
     _fields_ = [("origin", C.c_void_p), ("rotation", C.c_void_p), ("mouse", C.c_void_p), ("tris", C.c_void_p), ("n_tris", C.c_int64),
                 ("params", C.c_void_p), ("imp", C.c_void_p), ("ellip", C.c_void_p), ("bvhdata", C.c_void_p), ("bvhtree", C.c_void_p),
                 ("n_nodes", C.c_int64), ("leaf_tris", C.c_void_p), ("n_leaf_tris", C.c_int64), ("obj_indices", C.c_void_p), ("mtl", C.c_void_p),
-                ("n_mtl_floats", C.c_int64), ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32)]
+                ("n_mtl_floats", C.c_int64), ("sky", C.c_void_p), ("sky_w", C.c_int32), ("sky_h", C.c_int32),
+                ("tex", C.c_void_p), ("tex_w", C.c_void_p), ("tex_h", C.c_void_p), ("n_tex", C.c_int32)]
 
 
 def build():
@@ -48,7 +49,8 @@ def lib():
 class Scene:
     """Holds the SSBO contents (dict binding -> array) + texture 0 for the oracle."""
 
-    def __init__(self, buffers, sky):
+    def __init__(self, buffers, sky, textures=None):
+        """textures: optional {index: (h, w, 4) uint8} for the bindless table beyond the sky (index 0)"""
         f32 = lambda b: np.ascontiguousarray(buffers[b], dtype=np.float32)
         i32 = lambda b: np.ascontiguousarray(buffers[b], dtype=np.int32)
         self.keep = dict(origin=f32(0), rotation=f32(1), mouse=f32(2), tris=f32(3), params=f32(4), imp=f32(5), ellip=f32(7), bvhdata=f32(10),
@@ -65,11 +67,21 @@ class Scene:
         s.params, s.imp, s.ellip, s.bvhdata, s.bvhtree = p(k["params"]), p(k["imp"]), p(k["ellip"]), p(k["bvhdata"]), p(k["bvhtree"])
         s.n_nodes, s.leaf_tris, s.n_leaf_tris, s.obj_indices = buffers[11].size // 3, p(k["leaf"]), buffers[12].size, p(k["obj"])
         s.mtl, s.n_mtl_floats, s.sky, s.sky_w, s.sky_h = p(k["mtl"]), k["mtl"].size, p(k["sky"]), k["sky"].shape[1], k["sky"].shape[0]
+        tex = {0: k["sky"]}
+        for idx, arr in (textures or {}).items():
+            if idx != 0:
+                tex[int(idx)] = np.ascontiguousarray(arr, dtype=np.uint8)
+        n = max(tex) + 1
+        self.keep["tex"] = tex
+        self.keep["tex_ptr"] = (C.c_void_p * n)(*[tex[i].ctypes.data if i in tex else None for i in range(n)])
+        self.keep["tex_w"] = np.array([tex[i].shape[1] if i in tex else 0 for i in range(n)], np.int32)
+        self.keep["tex_h"] = np.array([tex[i].shape[0] if i in tex else 0 for i in range(n)], np.int32)
+        s.tex = C.cast(self.keep["tex_ptr"], C.c_void_p); s.tex_w = p(self.keep["tex_w"]); s.tex_h = p(self.keep["tex_h"]); s.n_tex = n
         self.c = s
 
     @classmethod
     def from_workload(cls, wl):
-        return cls(wl.buffers, wl.sky)
+        return cls(wl.buffers, wl.sky, getattr(wl, "textures", None))
 
 
 def render(scene, W, H, frame_count, seed, frame=None, nthreads=1, x0=0, xs=1, y0=0, ys=1, counters=None):

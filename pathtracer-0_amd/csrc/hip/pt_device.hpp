@@ -39,8 +39,11 @@ struct EllipRec {                                                               
 };
 struct MatRec {                                                                  // the mtl fields trace()/chooseRay()/directDiffuse() read
     float Kd[3], Ks[3], Ke[3], Tf[3]; float Tr, Ni, Density, Pm, Pr, Pc, Pcr, subsurface; int illum;
-    float Ka[3], ssColor[3], ssRadius[3]; int pad[2];                            // only directDiffuse (frag.glsl:661-675)
-};                                                                               // 32 dwords = 128 B
+    float Ka[3], ssColor[3], ssRadius[3];                                        // only directDiffuse (frag.glsl:661-675)
+    int hasMaps;                                                                 // any of the map_* below > -1
+    int map_Ka, map_Kd, map_Ks, map_Ke, map_Tr, map_Pm, map_Pr, map_Pc, map_norm; // texture indices (mapMtl :210-225, :827); -1 = none
+};                                                                               // 40 dwords = 160 B
+struct TexRec { const float4* data; int w, h; };                                 // one entry of the bindless table (binding 15), RGBA32F texels
 
 struct FrameConst {            // uniform per batch; written by k_frame_setup
     float screenSize, focalLength, resolution, screenHratio, SAMPLE_RES, MAX_BOUNCES, BLUR, FOCAL_DISTANCE, AUTO_FOCUS;
@@ -59,6 +62,7 @@ struct DevScene {
     const EllipRec* ellip; int numEllip;
     const MatRec* mats;   int numMat;
     const float4* sky;    int skyW, skyH;   // texture 0 as RGBA32F: texel = byte / 255.0f (the same binary32 division, done once at upload)
+    const TexRec* tex;    int numTex;       // the whole texture table (entry 0 = sky again)
     int ldsNodes, ldsTris;                   // how many leading node / triangle records the intersect kernel stages in LDS
 };
 
@@ -304,8 +308,7 @@ PM_DEV void removeFirstOfIndiceStack(Path& p) {
 
 // texture(textures[0], uv): GL 4.6 §8.14 LINEAR/REPEAT on RGBA8 (dispatch.java:349-354)
 PM_DEV int imod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
-PM_DEV vec3 sampleSky(const DevScene& sc, float u, float v) {
-    int w = sc.skyW, h = sc.skyH;
+PM_DEV vec3 sampleTex(const float4* tex, int w, int h, float u, float v) {
     float fu = u * (float)w - 0.5f, fv = v * (float)h - 0.5f;
     float flu = (__builtin_fabsf(fu) < 1.0e9f) ? __builtin_floorf(fu) : 0.0f;
     float flv = (__builtin_fabsf(fv) < 1.0e9f) ? __builtin_floorf(fv) : 0.0f;
@@ -313,12 +316,40 @@ PM_DEV vec3 sampleSky(const DevScene& sc, float u, float v) {
     int i0 = imod((int)flu, w), j0 = imod((int)flv, h);
     int i1 = imod(i0 + 1, w), j1 = imod(j0 + 1, h);
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-    float4 p00 = sc.sky[j0 * w + i0], p10 = sc.sky[j0 * w + i1], p01 = sc.sky[j1 * w + i0], p11 = sc.sky[j1 * w + i1];
+    float4 p00 = tex[j0 * w + i0], p10 = tex[j0 * w + i1], p01 = tex[j1 * w + i0], p11 = tex[j1 * w + i1];
     vec3 r;
     r.x = w00 * p00.x + w10 * p10.x + w01 * p01.x + w11 * p11.x;
     r.y = w00 * p00.y + w10 * p10.y + w01 * p01.y + w11 * p11.y;
     r.z = w00 * p00.z + w10 * p10.z + w01 * p01.z + w11 * p11.z;
     return r;
+}
+PM_DEV vec3 sampleSky(const DevScene& sc, float u, float v) { return sampleTex(sc.sky, sc.skyW, sc.skyH, u, v); }
+PM_DEV vec3 sampleTexture(const DevScene& sc, int index, float u, float v) {     // frag.glsl:79-81
+    const TexRec t = sc.tex[index];
+    return sampleTex(t.data, t.w, t.h, u, v);
+}
+// uv of a triangle hit (frag.glsl:508-517) from the shading record; (-1,-1) when the triangle has no vt (Q-7)
+PM_DEV void hitUV(const float4* S, float hu, float hv, float& uvx, float& uvy) {
+    float4 s1 = S[1], s2 = S[2], s3 = S[3];
+    float vt1x = s1.z, vt1y = s1.w;
+    if (vt1x != 69.420f) {
+        float w = 1.0f - hu - hv;
+        uvx = s2.x * hu + s2.z * hv + w * vt1x;
+        uvy = s2.y * hu + s3.x * hv + w * vt1y;
+        uvy = 1.0f - uvy;
+    } else { uvx = -1.0f; uvy = -1.0f; }
+}
+// mapMtl (frag.glsl:210-225) on the fields the render path reads, and the raw-texel normal of :827
+PM_DEV void applyMaps(const DevScene& sc, MatRec& m, float u, float v, vec3& N) {
+    if (m.map_Ka > -1) { vec3 t = sampleTexture(sc, m.map_Ka, u, v); m.Ka[0] = t.x * m.Ka[0]; m.Ka[1] = t.y * m.Ka[1]; m.Ka[2] = t.z * m.Ka[2]; }
+    if (m.map_Kd > -1) { vec3 t = sampleTexture(sc, m.map_Kd, u, v); m.Kd[0] = t.x * m.Kd[0]; m.Kd[1] = t.y * m.Kd[1]; m.Kd[2] = t.z * m.Kd[2]; }
+    if (m.map_Ks > -1) { vec3 t = sampleTexture(sc, m.map_Ks, u, v); m.Ks[0] = t.x; m.Ks[1] = t.y; m.Ks[2] = t.z; }
+    if (m.map_Ke > -1) { vec3 t = sampleTexture(sc, m.map_Ke, u, v); m.Ke[0] = t.x; m.Ke[1] = t.y; m.Ke[2] = t.z; }
+    if (m.map_Tr > -1) m.Tr = sampleTexture(sc, m.map_Tr, u, v).x;
+    if (m.map_Pm > -1) m.Pm = sampleTexture(sc, m.map_Pm, u, v).x;
+    if (m.map_Pr > -1) m.Pr = sampleTexture(sc, m.map_Pr, u, v).x;
+    if (m.map_Pc > -1) m.Pc = sampleTexture(sc, m.map_Pc, u, v).x;
+    if (m.map_norm > -1) N = sampleTexture(sc, m.map_norm, u, v);
 }
 PM_DEV vec3 bgCol(const DevScene& sc, vec3 In) {
     float u = 0.5f + atan2_(In.z, In.x) / (2.0f * 3.14159f);
@@ -412,7 +443,7 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
 
 // One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
 // Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
-template <bool TRANS>
+template <bool TRANS, bool TEX>
 PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, unsigned slot) {
     p.bounce++;                                               // :821
     const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
@@ -437,7 +468,12 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
             else N = vn2;                                                                                              // :506 (Q-4)
             mat = __float_as_int(s2.w);
         }
-        const MatRec m = sc.mats[mat];
+        MatRec m = sc.mats[mat];
+        if (TEX && m.hasMaps) {                               // mapMtl + map_norm (:826-827); ellipsoids with mapped materials are rejected at upload
+            float uvx, uvy;
+            hitUV(sc.shade + 4 * (size_t)prim, hu, hv, uvx, uvy);
+            applyMaps(sc, m, uvx, uvy, N);
+        }
         p.O = loc;                                            // :824
         ND = dot(N, D);
         N = N * (ND > 0.0f ? -1.0f : 1.0f);                   // :830
@@ -491,6 +527,7 @@ PM_DEV vec3 subsurfaceTint(const MatRec& m, vec3 o, vec3 loc) {
     vec3 sigma_t = v3(1.0f / rad.x, 1.0f / rad.y, 1.0f / rad.z);                                          // :671
     return exp3((-sigma_t) * si) * v3(m.ssColor[0], m.ssColor[1], m.ssColor[2]);                          // :672
 }
+template <bool TEX>
 PM_DEV bool directSegment(const DevScene& sc, Path& p, float ht, float hu, float hv, int prim) {
     if (p.probe) {                                            // second half of a subsurface sample: .loc of rayBVH is its (t,u,v) triple (:493)
         const MatRec m = sc.mats[__float_as_int(p.inc.x)];
@@ -519,7 +556,12 @@ PM_DEV bool directSegment(const DevScene& sc, Path& p, float ht, float hu, float
         else N = vn2;
         mat = __float_as_int(s2.w);
     }
-    const MatRec m = sc.mats[mat];
+    MatRec m = sc.mats[mat];
+    if (TEX && m.hasMaps) {
+        float uvx, uvy;
+        hitUV(sc.shade + 4 * (size_t)prim, hu, hv, uvx, uvy);
+        applyMaps(sc, m, uvx, uvy, N);
+    }
     vec3 Kd = v3(m.Kd[0], m.Kd[1], m.Kd[2]);
     vec3 col = v3(m.Ka[0], m.Ka[1], m.Ka[2]) + Kd * 0.2f + (Kd * dot(v3(0.0f, 1.0f, 0.0f), N)) + v3(m.Ke[0], m.Ke[1], m.Ke[2]);   // :661 (N not flipped)
     if (m.subsurface > 0.0f) {

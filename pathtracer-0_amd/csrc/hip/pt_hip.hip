@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
 // run one stream each.  Camera rays (6 Gaussian draws + transforms, the heaviest piece) are not computed by the lane
 // that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes all parked
 // rays densely after a barrier.
-template <bool TRANS, bool STATS, bool DIRECT>
+template <bool TRANS, bool STATS, bool DIRECT, bool TEX>
 __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
                                                  int nSlots, Control* ctl, PoolCtl* pc) {
     __shared__ unsigned sPerm[BLOCK], sFlags[BLOCK];
@@ -452,8 +452,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; p.g5dirty = false;
         p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
         isProbe = DIRECT && p.probe;
-        if (DIRECT) sampleDone = directSegment(sc, p, h.x, h.y, h.z, __float_as_int(h.w));      // RAYTRACING == 0 (frag.glsl:911-912)
-        else sampleDone = shadeSegment<TRANS>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, i);
+        if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w));      // RAYTRACING == 0 (frag.glsl:911-912)
+        else sampleDone = shadeSegment<TRANS, TEX>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, i);
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
             p.sample++;
@@ -630,8 +630,11 @@ struct pt_ctx {
     std::vector<float> origin, rotation, mouse, tris, params, imp, ellip, bvhdata, mtl;
     std::vector<int32_t> bvhtree, leaftris, objidx;
     std::vector<uint8_t> sky; int skyW = 0, skyH = 0;
+    struct HostTex { std::vector<uint8_t> rgba; int w = 0, h = 0; };
+    std::vector<HostTex> textures;          // bindless table beyond the sky (index 0 mirrors `sky`)
+    std::vector<float4*> dTexData; TexRec* dTexTable = nullptr;
     bool sceneDirty = true, frameInDirty = true;
-    bool trans = false, anySubsurface = false, ambiguousTriObj = false; int* dTriObj = nullptr;
+    bool trans = false, anySubsurface = false, ambiguousTriObj = false, anyMaps = false; int* dTriObj = nullptr;
     int stackDepth = 1;
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
@@ -705,18 +708,27 @@ int buildScene(pt_ctx* c) {
     if (me < 48) return fail(PT_ERR_SCENE, "mtlData[0] (floats per material) must be >= 48");
     int nMat = (int)((c->mtl.size() - 1) / me);
     std::vector<MatRec> mats(std::max(nMat, 1));
-    c->trans = false; c->anySubsurface = false;
+    c->trans = false; c->anySubsurface = false; c->anyMaps = false;
     for (int m = 0; m < nMat; m++) {
         const float* F = c->mtl.data() + (size_t)me * m;      // F[k] == mtlData[me*m + k]
-        static const int maps[] = {22, 23, 24, 32, 33, 34, 35, 37, 38, 39, 40, 41};
-        for (int k : maps) if ((int)F[k] > -1) return fail(PT_ERR_UNSUPPORTED, "material texture maps (map_* > -1) are not supported yet (SURVEY.md §8(f) N3)");
         MatRec& r = mats[m];
+        // map_* slots of the 48-float record (dispatch.java:295-315): Ka 22, Kd 23, Ks 24, Pm 32, Pr 33, Pc 35, bump/norm 37, Tr 39, Ke 41
+        // (map_Ps 34, map_Pcr 36, map_d 38, map_Ns 40 only change fields the render path never reads)
+        r.map_Ka = (int)F[22]; r.map_Kd = (int)F[23]; r.map_Ks = (int)F[24]; r.map_Pm = (int)F[32]; r.map_Pr = (int)F[33]; r.map_Pc = (int)F[35];
+        r.map_norm = (int)F[37]; r.map_Tr = (int)F[39]; r.map_Ke = (int)F[41];
+        r.hasMaps = 0;
+        for (int idx : {r.map_Ka, r.map_Kd, r.map_Ks, r.map_Ke, r.map_Tr, r.map_Pm, r.map_Pr, r.map_Pc, r.map_norm}) {
+            if (idx <= -1) continue;
+            r.hasMaps = 1;
+            if ((size_t)idx >= c->textures.size() || c->textures[idx].rgba.empty())
+                return fail(PT_ERR_SCENE, "a material names a texture index that was never uploaded with pt_set_texture");
+        }
         for (int k = 0; k < 3; k++) { r.Kd[k] = F[4 + k]; r.Ks[k] = F[7 + k]; r.Tf[k] = F[13 + k]; r.Ke[k] = F[17 + k]; }
         r.Tr = F[12]; r.Ni = F[16]; r.Density = F[20]; r.illum = (int)F[21]; r.Pm = F[25]; r.Pr = F[26]; r.Pc = F[28]; r.Pcr = F[29]; r.subsurface = F[42];
         for (int k = 0; k < 3; k++) { r.Ka[k] = F[1 + k]; r.ssColor[k] = F[43 + k]; r.ssRadius[k] = F[46 + k]; }
-        r.pad[0] = r.pad[1] = 0;
-        if (r.Tr > 0.0f || r.Tf[0] > 0.0f || r.illum == 5 || r.illum == 7) c->trans = true;
+        if (r.Tr > 0.0f || r.Tf[0] > 0.0f || r.illum == 5 || r.illum == 7 || r.map_Tr > -1) c->trans = true;   // (a Tr map can switch transmission on)
         if (r.subsurface > 0.0f) c->anySubsurface = true;
+        if (r.hasMaps) c->anyMaps = true;
     }
     // objects / BVH
     int numObj = c->objidx[0];
@@ -812,6 +824,7 @@ int buildScene(pt_ctx* c) {
         for (int k = 0; k < 3; k++) { r.c[k] = E[1 + 3 * i + k]; r.st[k] = E[1 + nE * 3 + 3 * i + k]; r.rot[k] = E[1 + nE * 6 + 3 * i + k]; }
         r.r = E[1 + nE * 9 + i]; r.mat = (int)E[1 + nE * 10 + i];
         if (r.mat < 0 || r.mat >= nMat) return fail(PT_ERR_SCENE, "ellipsoid material index out of range");
+        if (mats[r.mat].hasMaps) return fail(PT_ERR_UNSUPPORTED, "ellipsoids with texture-mapped materials: the shader samples them at the uv of the closest triangle behind them (hitUV is not reset, frag.glsl:574 vs :619-630) - not restated on the device");
     }
     // upload
     hipStream_t s = c->stream;
@@ -828,11 +841,27 @@ int buildScene(pt_ctx* c) {
     for (size_t k = 0; k < skyf.size(); k++)
         skyf[k] = f4((float)c->sky[4 * k] / 255.0f, (float)c->sky[4 * k + 1] / 255.0f, (float)c->sky[4 * k + 2] / 255.0f, (float)c->sky[4 * k + 3] / 255.0f);
     if ((rc = uploadVec((void**)&c->dSky, skyf.data(), skyf.size() * 16, s))) return rc;
+    for (float4* p : c->dTexData) if (p) HIP_TRY(hipFree(p));
+    c->dTexData.assign(std::max<size_t>(c->textures.size(), 1), nullptr);
+    std::vector<TexRec> table(c->dTexData.size());
+    table[0].data = c->dSky; table[0].w = c->skyW; table[0].h = c->skyH;
+    for (size_t ti = 1; ti < c->textures.size(); ti++) {
+        const pt_ctx::HostTex& T = c->textures[ti];
+        table[ti].data = nullptr; table[ti].w = T.w; table[ti].h = T.h;
+        if (T.rgba.empty()) continue;
+        std::vector<float4> tf((size_t)T.w * T.h);
+        for (size_t k = 0; k < tf.size(); k++)
+            tf[k] = f4((float)T.rgba[4 * k] / 255.0f, (float)T.rgba[4 * k + 1] / 255.0f, (float)T.rgba[4 * k + 2] / 255.0f, (float)T.rgba[4 * k + 3] / 255.0f);
+        HIP_TRY(hipMalloc((void**)&c->dTexData[ti], tf.size() * 16));
+        HIP_TRY(hipMemcpy(c->dTexData[ti], tf.data(), tf.size() * 16, hipMemcpyHostToDevice));
+        table[ti].data = c->dTexData[ti];
+    }
+    if ((rc = uploadVec((void**)&c->dTexTable, table.data(), table.size() * sizeof(TexRec), s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     DevScene& sc = c->sc;
     sc.nodes = c->dNodes; sc.nNodes = (int)order.size(); sc.tris = c->dTris; sc.nTriRecs = (int)(triRecs.size() / 3);
     sc.shade = c->dShade; sc.nTris = (int)nTris; sc.triObj = c->dTriObj; sc.roots = c->dRoots; sc.numObj = numObj; sc.ellip = c->dEllip; sc.numEllip = nE;
-    sc.mats = c->dMats; sc.numMat = nMat; sc.sky = c->dSky; sc.skyW = c->skyW; sc.skyH = c->skyH;
+    sc.mats = c->dMats; sc.numMat = nMat; sc.sky = c->dSky; sc.skyW = c->skyW; sc.skyH = c->skyH; sc.tex = c->dTexTable; sc.numTex = (int)table.size();
     // LDS tile: as many leading (top-of-tree) node records and triangle records as the budget allows
     int budget = c->ldsBudget - c->stackDepth * BLOCK * 4;
     int ln = 0, lt = 0;
@@ -1039,9 +1068,13 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
                     HIP_TRY(hipEventRecord(lastExtend, ps));
                 }
 #define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, ps, c->sc, b, c->dFc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl, pr.pc
-                if (direct) { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, true, true>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, false, true>), SHADE_ARGS)); }
-                else if (c->trans) { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, true, false>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<true, false, false>), SHADE_ARGS)); }
-                else { if (c->countStats) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, true, false>), SHADE_ARGS)); else TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<false, false, false>), SHADE_ARGS)); }
+                // kernel variant: transmissive materials present / statistics on / RAYTRACING == 0 / texture-mapped materials present
+#define SHADE_V(T, S, D, X) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
+#define SHADE_S(T, D, X) do { if (c->countStats) SHADE_V(T, true, D, X); else SHADE_V(T, false, D, X); } while (0)
+#define SHADE_X(T, D) do { if (c->anyMaps) SHADE_S(T, D, true); else SHADE_S(T, D, false); } while (0)
+                if (direct) SHADE_X(false, true);
+                else if (c->trans) SHADE_X(true, false);
+                else SHADE_X(false, false);
             }
             iters++;
         }
@@ -1144,7 +1177,8 @@ int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
+    for (float4* p : c->dTexData) if (p) hipFree(p);
+    void* ptrs[] = {c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dPool};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hAlive) hipHostFree(c->hAlive);
@@ -1185,8 +1219,11 @@ int pt_set_buffer(pt_ctx* c, int binding, const void* data, size_t bytes) {
 
 int pt_set_texture(pt_ctx* c, int index, int w, int h, const uint8_t* rgba8) {
     if (!c || !rgba8 || w < 1 || h < 1) return fail(PT_ERR_ARG, "pt_set_texture: bad argument");
-    if (index != 0) return fail(PT_ERR_UNSUPPORTED, "only texture 0 (sky) is read by the render path; material maps are SURVEY.md §8(f) N3");
-    c->sky.assign(rgba8, rgba8 + (size_t)w * h * 4); c->skyW = w; c->skyH = h; c->sceneDirty = true;
+    if (index < 0 || index > 4095) return fail(PT_ERR_ARG, "texture index out of range [0,4095]");
+    if (index == 0) { c->sky.assign(rgba8, rgba8 + (size_t)w * h * 4); c->skyW = w; c->skyH = h; }
+    if ((size_t)index >= c->textures.size()) c->textures.resize((size_t)index + 1);
+    c->textures[index].rgba.assign(rgba8, rgba8 + (size_t)w * h * 4); c->textures[index].w = w; c->textures[index].h = h;
+    c->sceneDirty = true;
     return PT_OK;
 }
 

@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <dirent.h>
+#include <sys/stat.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -119,6 +121,7 @@ constexpr int NUM_MATERIAL_PARAMETERS = 48; // :97
 
 struct pts_scene {
     std::vector<material> materials;
+    std::vector<std::string> textures, textureNames;      // dispatch.java:95-96
     std::vector<triangle> triangles;
     int NEXT_TRI_ID = 0;
     // implicits
@@ -351,6 +354,98 @@ const Field kFields[] = {FV(Ka), FV(Kd), FV(Ks), FD(Ns), FD(d), FD(Tr), FV(Tf), 
                          FD(Pm), FD(Pr), FD(Ps), FD(Pc), FD(Pcr), FD(aniso), FD(anisor), FI(map_Pm), FI(map_Pr), FI(map_Ps), FI(map_Pc), FI(map_Pcr),
                          FI(map_bump), FI(map_d), FI(map_Tr), FI(map_Ns), FI(map_Ke), FD(Density), FD(subsurface), FV(subsurfaceColor), FV(subsurfaceRadius)};
 
+std::vector<std::string> splitSpace(const std::string& line) {         // String.split(" "): single spaces, trailing empties dropped
+    std::vector<std::string> out; std::string cur;
+    for (char ch : line) { if (ch == ' ') { out.push_back(cur); cur.clear(); } else cur.push_back(ch); }
+    out.push_back(cur);
+    while (!out.empty() && out.back().empty()) out.pop_back();
+    return out;
+}
+
+// material.parseMtls :1319-1512
+int parseMtls(pts_scene* s, const std::string& filePath, const std::string& parentDirectoryPath) {
+    std::ifstream in(filePath);
+    if (!in) return fail(-40, "cannot open MTL file: " + filePath + " (reference: RuntimeException(IOException), dispatch.java:1510)");
+    std::string line;
+    auto num = [&](const std::vector<std::string>& v, size_t i, double& out) {
+        return i < v.size() && parseD(trim(v[i]), out);
+    };
+    auto nextLine = [&](std::string& l) { if (!std::getline(in, l)) return false; if (!l.empty() && l.back() == '\r') l.pop_back(); return true; };
+    while (nextLine(line)) {
+        if (!startsWith(line, "newmtl ")) continue;
+        auto parts = splitSpace(line);
+        if (parts.size() < 2) return fail(-41, "newmtl without a name");
+        material mat;
+        mat.name = trim(parts[1]) + parentDirectoryPath;
+        while (nextLine(line) && !line.empty()) {
+            std::replace(line.begin(), line.end(), '/', '\\');                 // :1330
+            auto vals = splitSpace(line);
+            auto vec3v = [&](vec& out) { double a, b, c; if (!num(vals, 1, a) || !num(vals, 2, b) || !num(vals, 3, c)) return false; out = vec(a, b, c); return true; };
+            auto scal = [&](double& out) { return num(vals, 1, out); };
+            auto tex = [&](int& slot) {
+                if (vals.size() < 2) return fail(-42, "MTL map line without a file name");
+                std::string name = trim(vals[1]);
+                auto it = std::find(s->textureNames.begin(), s->textureNames.end(), name);
+                if (it != s->textureNames.end()) { slot = (int)(it - s->textureNames.begin()); return 0; }
+                slot = (int)s->textures.size();
+                std::string file = name; std::replace(file.begin(), file.end(), '\\', '/');      // platform path separator
+                std::string path = parentDirectoryPath + "/" + file;
+                std::ifstream probe(path);
+                if (!probe) return fail(-43, "cannot read texture file: " + path + " (reference: RuntimeException from parseTexture, dispatch.java:1573)");
+                s->textureNames.push_back(name); s->textures.push_back(path);                    // parseTexture :1552-1575
+                return 0;
+            };
+            bool ok = true; int rc = 0;
+            if (startsWith(line, "Ka ")) ok = vec3v(mat.Ka);
+            else if (startsWith(line, "Kd ")) ok = vec3v(mat.Kd);
+            else if (startsWith(line, "Ks ")) ok = vec3v(mat.Ks);
+            else if (startsWith(line, "Ns ")) ok = scal(mat.Ns);
+            else if (startsWith(line, "d ")) { ok = scal(mat.d); mat.Tr = 1 - mat.d; }
+            else if (startsWith(line, "Tr ")) { ok = scal(mat.Tr); mat.d = 1 - mat.Tr; }
+            else if (startsWith(line, "Tf ")) ok = vec3v(mat.Tf);
+            else if (startsWith(line, "Ni ")) ok = scal(mat.Ni);
+            else if (startsWith(line, "Ke ")) { ok = vec3v(mat.Ke); mat.Density = mat.Ke.magnitude(); }
+            else if (startsWith(line, "Density ")) ok = scal(mat.Density);
+            else if (startsWith(line, "illum ")) { int v = 0; ok = vals.size() > 1 && parseI(trim(vals[1]), v); mat.illum = v; }
+            else if (startsWith(line, "map_Ka ")) rc = tex(mat.map_Ka);
+            else if (startsWith(line, "map_Kd ")) rc = tex(mat.map_Kd);
+            else if (startsWith(line, "map_Ks ")) rc = tex(mat.map_Ks);
+            else if (startsWith(line, "Pm ")) ok = scal(mat.Pm);
+            else if (startsWith(line, "Pr ")) ok = scal(mat.Pr);
+            else if (startsWith(line, "Ps ")) ok = scal(mat.Ps);
+            else if (startsWith(line, "Pc ")) ok = scal(mat.Pc);
+            else if (startsWith(line, "Pcr ")) ok = scal(mat.Pcr);
+            else if (startsWith(line, "aniso ")) ok = scal(mat.aniso);
+            else if (startsWith(line, "anisor ")) ok = scal(mat.anisor);
+            else if (startsWith(line, "map_Pm ")) rc = tex(mat.map_Pm);
+            else if (startsWith(line, "map_Pr ") || startsWith(line, "refl")) rc = tex(mat.map_Pr);
+            else if (startsWith(line, "map_Ps ")) rc = tex(mat.map_Ps);
+            else if (startsWith(line, "map_Pc ")) rc = tex(mat.map_Pc);
+            else if (startsWith(line, "map_Pcr ")) rc = tex(mat.map_Pcr);
+            else if (startsWith(line, "map_Bump ") || startsWith(line, "bump ") || startsWith(line, "map_bump ")) rc = tex(mat.map_bump);
+            else if (startsWith(line, "map_d ")) rc = tex(mat.map_d);
+            else if (startsWith(line, "map_Tr ")) rc = tex(mat.map_Tr);
+            else if (startsWith(line, "map_Ns ")) rc = tex(mat.map_Ns);
+            else if (startsWith(line, "map_Ke ")) rc = tex(mat.map_Ke);
+            else if (startsWith(line, "subsurface ")) ok = scal(mat.subsurface);
+            else if (startsWith(line, "subsurfaceColor ")) ok = vec3v(mat.subsurfaceColor);
+            else if (startsWith(line, "subsurfaceRadius ")) ok = vec3v(mat.subsurfaceRadius);
+            if (rc) return rc;
+            if (!ok) return fail(-44, "MTL: cannot parse numbers in line '" + line + "' (reference: NumberFormatException)");
+        }
+        s->materials.push_back(mat);
+    }
+    s->packed = false;
+    return 0;
+}
+
+bool endsWithCI(const std::string& s, const char* ext) {
+    size_t n = std::strlen(ext);
+    if (s.size() < n) return false;
+    for (size_t i = 0; i < n; i++) if (std::tolower((unsigned char)s[s.size() - n + i]) != ext[i]) return false;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -386,8 +481,39 @@ int pts_add_object_text(pts_scene* s, const char* obj_text, size_t len, int mate
     std::istringstream in(std::string(obj_text, len));
     return parseObj(s, in, material, vec(scale[0], scale[1], scale[2]), vec(shift[0], shift[1], shift[2]), vec(rot[0], rot[1], rot[2]), parent_directory);
 }
+int pts_add_texture(pts_scene* s, const char* path, const char* name) {
+    s->textures.push_back(path ? path : ""); s->textureNames.push_back(name ? name : "");
+    return (int)s->textures.size() - 1;
+}
+int pts_texture_count(pts_scene* s) { return (int)s->textures.size(); }
+const char* pts_texture_path(pts_scene* s, int i) { return (i >= 0 && (size_t)i < s->textures.size()) ? s->textures[i].c_str() : ""; }
+const char* pts_texture_name(pts_scene* s, int i) { return (i >= 0 && (size_t)i < s->textureNames.size()) ? s->textureNames[i].c_str() : ""; }
+int pts_parse_mtls(pts_scene* s, const char* mtl_path, const char* parent_directory) { return parseMtls(s, mtl_path, parent_directory ? parent_directory : "null"); }
+
 int pts_add_object(pts_scene* s, const char* obj_path, int material, const double scale[3], const double shift[3], const double rot[3],
                    const char* parent_directory) {
+    struct stat sb;
+    if (stat(obj_path, &sb) == 0 && S_ISDIR(sb.st_mode)) {                    // scene.addObject on a directory, :869-882
+        std::vector<std::string> mtls, objs;
+        if (DIR* d = opendir(obj_path)) {
+            while (dirent* e = readdir(d)) {
+                std::string n = e->d_name;
+                if (endsWithCI(n, ".mtl")) mtls.push_back(n); else if (endsWithCI(n, ".obj")) objs.push_back(n);
+            }
+            closedir(d);
+        }
+        std::sort(mtls.begin(), mtls.end()); std::sort(objs.begin(), objs.end());
+        if (objs.empty()) return fail(-24, "no obj files found in the directory.");
+        std::string dir = obj_path;
+        for (const std::string& m : mtls) { int rc = parseMtls(s, dir + "/" + m, dir); if (rc) return rc; }
+        for (const std::string& o : objs) {
+            std::ifstream in(dir + "/" + o);
+            if (!in) return fail(-23, "cannot open OBJ file: " + dir + "/" + o);
+            int rc = parseObj(s, in, material, vec(scale[0], scale[1], scale[2]), vec(shift[0], shift[1], shift[2]), vec(rot[0], rot[1], rot[2]), dir.c_str());
+            if (rc) return rc;
+        }
+        return 0;
+    }
     std::ifstream in(obj_path);
     if (!in) return fail(-23, std::string("cannot open OBJ file: ") + obj_path);   // reference prints the IOException and continues
     return parseObj(s, in, material, vec(scale[0], scale[1], scale[2]), vec(shift[0], shift[1], shift[2]), vec(rot[0], rot[1], rot[2]), parent_directory);

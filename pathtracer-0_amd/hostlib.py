@@ -35,6 +35,11 @@ def _lib():
         L.pts_add_tri.argtypes = [C.c_void_p, d3, d3, d3, C.c_int]
         L.pts_add_ellipsoid.argtypes = [C.c_void_p, d3, d3, d3, C.c_float, C.c_int]
         L.pts_add_implicit.argtypes = [C.c_void_p, C.c_int, d3, d3, d3, C.c_int]
+        L.pts_add_texture.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.pts_texture_count.argtypes = [C.c_void_p]
+        L.pts_texture_path.argtypes = [C.c_void_p, C.c_int]; L.pts_texture_path.restype = C.c_char_p
+        L.pts_texture_name.argtypes = [C.c_void_p, C.c_int]; L.pts_texture_name.restype = C.c_char_p
+        L.pts_parse_mtls.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         L.pts_pack.argtypes = [C.c_void_p]
         L.pts_get_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.pts_count.argtypes = [C.c_void_p, C.c_int]
@@ -76,6 +81,28 @@ class Scene:
         vals = [float(val)] if np.isscalar(val) else [float(x) for x in val]
         arr = (C.c_double * len(vals))(*vals)
         self._check(self._L.pts_set_last_mtl(self._h, prop.encode(), arr, len(vals)))
+
+    def addTexture(self, path, name):
+        """textures.add(path); textureNames.add(name) (dispatch.java:221-222: the sky is entry 0) -> index"""
+        return self._check(self._L.pts_add_texture(self._h, path.encode(), name.encode()))
+
+    def textures(self):
+        """[(path, name)] of the texture table: entry i goes to pt_set_texture(i, ...) once decoded"""
+        n = self._L.pts_texture_count(self._h)
+        return [(self._L.pts_texture_path(self._h, i).decode(), self._L.pts_texture_name(self._h, i).decode()) for i in range(n)]
+
+    def load_textures(self):
+        """{index: (h, w, 4) uint8} decoded like stbi_load(path, 4 channels) does (dispatch.java:343): top row first"""
+        from PIL import Image
+        out = {}
+        for i, (path, _) in enumerate(self.textures()):
+            if path and os.path.exists(path):
+                out[i] = np.asarray(Image.open(path).convert("RGBA"), dtype=np.uint8).copy()
+        return out
+
+    def parseMtls(self, filePath, parentDirectoryPath):
+        pd = None if parentDirectoryPath is None else parentDirectoryPath.encode()
+        self._check(self._L.pts_parse_mtls(self._h, filePath.encode(), pd))
 
     def addObject(self, filepath, material, scale=1.0, shift=0.0, rot=0.0, parentDirectory=None):
         pd = None if parentDirectory is None else parentDirectory.encode()

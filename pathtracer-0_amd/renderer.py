@@ -116,6 +116,8 @@ class Renderer:
         for b, arr in wl.buffers.items():
             self.set_buffer(b, arr)
         self.set_texture(0, wl.sky)
+        for idx, arr in getattr(wl, "textures", {}).items():
+            self.set_texture(idx, arr)
 
     # --- frame loop ---------------------------------------------------------------------------
     def reset_frame(self):

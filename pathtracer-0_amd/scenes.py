@@ -67,6 +67,18 @@ class Obj:
         self.f(i[0], i[1], i[2], k)
         self.f(i[0], i[2], i[3], k)
 
+    def quad_uv(self, p0, p1, p2, p3, n, uv0=(0.05, 0.05), uv1=(0.95, 0.95)):
+        """quad with texture coordinates (first vt.y must not be 0: the packer reads that as "no uv")"""
+        i = [self.v(p) for p in (p0, p1, p2, p3)]
+        k = self.vn(n)
+        t = []
+        for (a, b) in ((uv0[0], uv0[1]), (uv1[0], uv0[1]), (uv1[0], uv1[1]), (uv0[0], uv1[1])):
+            self.lines.append("vt %.9g %.9g" % (a, b))
+            self.nt = getattr(self, "nt", 0) + 1
+            t.append(self.nt)
+        self.lines.append(f"f {i[0]}/{t[0]}/{k} {i[1]}/{t[1]}/{k} {i[2]}/{t[2]}/{k}")
+        self.lines.append(f"f {i[0]}/{t[0]}/{k} {i[2]}/{t[2]}/{k} {i[3]}/{t[3]}/{k}")
+
     def box(self, center, half, yrot):
         """axis-aligned box of half extents `half` rotated by yrot about +y, 12 triangles, flat normals."""
         c, s = math.cos(yrot), math.sin(yrot)
@@ -155,10 +167,11 @@ def displaced_torus(nu, nv_, center, R, r, amp, seed):
 class Workload:
     """Everything the render call consumes: SSBO contents by binding point + texture 0 + config."""
 
-    def __init__(self, name, W, H, buffers, sky, sample_res, max_bounces, info):
+    def __init__(self, name, W, H, buffers, sky, sample_res, max_bounces, info, textures=None):
         self.name, self.W, self.H = name, W, H
         self.buffers = buffers            # {binding: np.ndarray}: 0,1,2,3,4,5,7,10,11,12,13,14
         self.sky = sky                    # (h, w, 4) uint8, texture index 0
+        self.textures = dict(textures or {})   # {index >= 1: (h, w, 4) uint8}: the rest of the bindless table (binding 15)
         self.sample_res, self.max_bounces = sample_res, max_bounces
         self.info = info
 
@@ -169,7 +182,7 @@ class Workload:
             p[names.index(k)] = v
         b = dict(self.buffers)
         b[4] = p
-        return Workload(self.name, self.W, self.H, b, self.sky, int(p[4]), int(p[5]), self.info)
+        return Workload(self.name, self.W, self.H, b, self.sky, int(p[4]), int(p[5]), self.info, self.textures)
 
 
 def _finish(name, sc, W, H, cam, rot, sky_rgb, sample_res, max_bounces, **pk):
@@ -349,10 +362,84 @@ def c5_clearcoat_sss(W=3840, H=2160, sample_res=8, max_bounces=16, subdiv=4):
     return _finish("C5", sc, W, H, CORNELL_CAM, CORNELL_ROT, (0, 0, 0), sample_res, max_bounces)
 
 
+def t1_textured(W=96, H=54, sample_res=8, max_bounces=8):
+    """Texture-map workload (not a BASELINE config): Cornell room whose floor has a checker map_Kd, whose back
+    wall carries map_Ke + map_Ks, a box with map_Pr / map_Pm / map_Pc / map_Tr, and a panel shaded through a raw-texel map_bump."""
+    rs = np.random.RandomState(11)
+
+    def tex(h, w, fn):
+        a = np.zeros((h, w, 4), np.uint8)
+        for j in range(h):
+            for i in range(w):
+                a[j, i, :3] = fn(i, j)
+        a[..., 3] = 255
+        return a
+
+    textures = {
+        1: tex(8, 8, lambda i, j: (230, 230, 230) if (i + j) % 2 else (40, 60, 200)),                      # checker albedo
+        2: tex(4, 16, lambda i, j: (255, 200, 120) if i % 4 == 0 else (0, 0, 0)),                           # emissive stripes
+        3: tex(5, 7, lambda i, j: tuple(int(v) for v in rs.randint(0, 256, 3))),                              # noise (Ks / Pr / Pm / Pc / Tr source)
+        4: tex(2, 2, lambda i, j: (60, 230, 90)),                                                             # "normal" texels, used raw (frag.glsl:827)
+    }
+    sc = hostlib.Scene()
+    _cornell_materials(sc)
+    sc.addMaterial("floor"); sc.setLastMtl("Kd", (0.9, 0.9, 0.9)); sc.setLastMtl("Pr", 1); sc.setLastMtl("map_Kd", 1)
+    sc.addMaterial("glow"); sc.setLastMtl("Kd", (0.5, 0.5, 0.5)); sc.setLastMtl("Pr", 1); sc.setLastMtl("map_Ke", 2); sc.setLastMtl("map_Ks", 3); sc.setLastMtl("Pc", 0.3)
+    sc.addMaterial("mixed"); sc.setLastMtl("Kd", (0.8, 0.7, 0.6)); sc.setLastMtl("map_Pr", 3); sc.setLastMtl("map_Pm", 3); sc.setLastMtl("map_Pc", 3)
+    sc.setLastMtl("map_Tr", 3); sc.setLastMtl("Ni", 1.3); sc.setLastMtl("map_Ka", 1); sc.setLastMtl("Ka", (0.1, 0.1, 0.1))
+    sc.addMaterial("bumped"); sc.setLastMtl("Kd", (0.7, 0.7, 0.7)); sc.setLastMtl("Pr", 1); sc.setLastMtl("map_bump", 4)
+    o = Obj()
+    o.group("room")
+    o.usemtl("floor")
+    o.quad_uv((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1), (0, 1, 0), (0.05, 0.05), (3.95, 3.95))
+    o.usemtl("white")
+    o.quad((-1, 2, -1), (-1, 2, 1), (1, 2, 1), (1, 2, -1), (0, -1, 0))
+    o.usemtl("glow")
+    o.quad_uv((-1, 0, 1), (1, 0, 1), (1, 2, 1), (-1, 2, 1), (0, 0, -1))
+    o.usemtl("red")
+    o.quad((1, 0, -1), (1, 2, -1), (1, 2, 1), (1, 0, 1), (-1, 0, 0))
+    o.usemtl("green")
+    o.quad((-1, 0, -1), (-1, 0, 1), (-1, 2, 1), (-1, 2, -1), (1, 0, 0))
+    o.group("light")
+    o.usemtl("light")
+    o.quad((-0.25, 1.98, -0.25), (0.25, 1.98, -0.25), (0.25, 1.98, 0.25), (-0.25, 1.98, 0.25), (0, -1, 0))
+    o.group("panel")
+    o.usemtl("bumped")
+    o.quad_uv((-0.9, 0.2, 0.2), (-0.3, 0.2, -0.4), (-0.3, 1.2, -0.4), (-0.9, 1.2, 0.2), (0.7, 0.1, -0.7))
+    o.usemtl("mixed")
+    o.quad_uv((0.2, 0.1, 0.3), (0.9, 0.1, -0.2), (0.9, 1.0, -0.2), (0.2, 1.0, 0.3), (-0.58, 0.05, -0.81))
+    sc.addObjectText(o.text(), 0, parentDirectory="")
+    wl = _finish("T1", sc, W, H, CORNELL_CAM, CORNELL_ROT, (30, 40, 60), sample_res, max_bounces)
+    wl.textures = textures
+    return wl
+
+
+def asset_workload(directory, W, H, cam=CORNELL_CAM, rot=CORNELL_ROT, sky=(30, 40, 60), sample_res=8, max_bounces=8, name="asset",
+                   scale=1.0, shift=0.0, rotate=0.0, **pk):
+    """The reference's way of loading a model (dispatch.java:219-229 + :869-882): texture 0 is the sky, then
+    scene.addObject(<directory>) parses every .mtl (registering the map files) and every .obj in it; the decoded images fill
+    the rest of the texture table.  `sky` is an RGB triple or a path to an image."""
+    sc = hostlib.Scene()
+    sky_img = sky
+    if isinstance(sky, str):
+        from PIL import Image
+        sc.addTexture(sky, "skybox.png")
+        sky_img = np.asarray(Image.open(sky).convert("RGBA"), dtype=np.uint8).copy()
+    else:
+        sc.addTexture("", "skybox.png")
+    sc.addMaterial("default")
+    sc.addObject(directory, 0, scale, shift, rotate)
+    wl = _finish(name, sc, W, H, cam, rot, sky_img, sample_res, max_bounces, **pk)
+    wl.textures = {i: a for i, a in sc.load_textures().items() if i >= 1}
+    return wl
+
+
 BUILDERS = {"C1": c1_spheres, "C2": c2_cornell, "C3": c3_glass_metal, "C4": c4_mesh, "C5": c5_clearcoat_sss}
 
 
 def build(name, W=None, H=None, **kw):
+    if name == "T1":
+        return t1_textured(W or 96, H or 54, **kw)
     cfg = CONFIGS[name]
     W = cfg["W"] if W is None else W
     H = cfg["H"] if H is None else H

@@ -346,3 +346,54 @@ def test_n2_direct_diffuse_mode(pt, oracle, renderer_mod, name, mode):
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, extend_mode=mode)
     assert_same(got, ref, cnt, ocnt)
     assert cnt["segments"] == cnt["samples"]
+
+
+@pytest.mark.parametrize("raytracing", [1, 0])
+def test_n3_texture_maps(pt, oracle, renderer_mod, raytracing):
+    """material texture maps (mapMtl, frag.glsl:210-225) + the raw-texel normal map (:827), in both render modes"""
+    wl = pt.scenes.build("T1", 96, 54).with_params(RAYTRACING=raytracing)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
+    assert_same(got, ref, cnt, ocnt)
+    # the maps matter: the same scene without its textures renders differently
+    b = dict(wl.buffers); m = b[14].copy().reshape(-1)
+    for mat in range((len(m) - 1) // 48):
+        for k in (22, 23, 24, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41):
+            m[48 * mat + k] = -1.0
+    b[14] = m
+    plain = pt.scenes.Workload(wl.name, wl.W, wl.H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    got2, ref2, _, _ = render_both(pt, oracle, renderer_mod, plain, 3, count_stats=False)
+    assert_same(got2, ref2)
+    assert rmse(got, got2) > 1e-2
+
+
+def test_n3_asset_directory(pt, oracle, renderer_mod, tmp_path):
+    """the reference's loading path end to end: addObject(<directory>) -> parseMtls -> texture table -> render (dispatch.java:869-882)"""
+    from test_host_scene import _asset_dir
+    wl = pt.scenes.asset_workload(_asset_dir(tmp_path), 80, 48, sample_res=4, max_bounces=6)
+    assert sorted(wl.textures) == [1, 2, 3]
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
+    assert_same(got, ref, cnt, ocnt)
+    assert got[..., :3].max() > 0
+
+
+def test_n3_missing_texture_and_mapped_ellipsoid_are_errors(pt, renderer_mod):
+    wl = pt.scenes.build("T1", 64, 36)
+    r = renderer_mod.Renderer(64, 36)
+    for bnd, arr in wl.buffers.items():
+        r.set_buffer(bnd, arr)
+    r.set_texture(0, wl.sky)                      # material textures 1..4 never uploaded
+    with pytest.raises(renderer_mod.PtError) as e:
+        r.render(1, 1)
+    assert e.value.code == -4
+    r.close()
+    wl1 = pt.scenes.build("C1", 64, 64)
+    b = dict(wl1.buffers); m = b[14].copy(); m[23] = 0.0   # material 0 (also on an ellipsoid): map_Kd = texture 0
+    b[14] = m
+    r = renderer_mod.Renderer(64, 64)
+    for bnd, arr in b.items():
+        r.set_buffer(bnd, arr)
+    r.set_texture(0, wl1.sky)
+    with pytest.raises(renderer_mod.PtError) as e:
+        r.render(1, 1)
+    assert e.value.code == -5
+    r.close()

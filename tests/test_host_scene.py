@@ -146,3 +146,106 @@ def test_workloads_build_and_are_deterministic(pt):
     assert pt.scenes.build("C2", 64, 36).info["triangles"] == 36
     assert pt.scenes.build("C3", 64, 36).info["triangles"] == 12 + 2 * 1280
     assert [pt.scenes.frame_seed(f) for f in (1, 2, 3)] == [9153, 7072, 4991]
+
+
+# ---- material.parseMtls + scene.addObject on a directory (dispatch.java:869-882, :1319-1512, :1552-1575)
+MTL = """# comment
+newmtl wood
+Ka 0.1 0.2 0.3
+Kd 0.5 0.6 0.7
+Ks 0.25 0.25 0.25
+Ns 96
+d 0.75
+Ni 1.45
+illum 2
+map_Kd tex/wood.png
+map_Bump tex/bump.png
+Pr 0.4
+subsurfaceColor 1 0.5 0.25
+
+newmtl lamp
+Ke 3 4 0
+Tr 0.25
+map_Ke tex/wood.png
+refl tex/rough.png
+"""
+
+QUADS = """o floor
+usemtl wood
+v -1 0 -1
+v 1 0 -1
+v 1 0 1
+v -1 0 1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 1 0
+f 1/1/1 2/2/1 3/3/1
+f 1/1/1 3/3/1 4/4/1
+o panel
+usemtl lamp
+v -1 2 -1
+v 1 2 -1
+v 1 2 1
+v -1 2 1
+f 5/1/1 6/2/1 7/3/1
+f 5/1/1 7/3/1 8/4/1
+"""
+
+
+def _asset_dir(tmp_path):
+    from PIL import Image
+    d = tmp_path / "asset"; (d / "tex").mkdir(parents=True)
+    (d / "a.mtl").write_text(MTL); (d / "b.OBJ").write_text(QUADS)
+    rng = np.random.default_rng(5)
+    for name, mode in (("wood", "RGB"), ("bump", "RGBA"), ("rough", "L")):
+        ch = {"RGB": 3, "RGBA": 4, "L": 1}[mode]
+        a = rng.integers(0, 256, (6, 5, ch), dtype=np.uint8)
+        Image.fromarray(a[..., 0] if ch == 1 else a, mode).save(d / "tex" / f"{name}.png")
+    return str(d)
+
+
+def test_parse_mtls_and_directory_import(pt, tmp_path):
+    d = _asset_dir(tmp_path)
+    sc = pt.hostlib.Scene()
+    assert sc.addTexture("sky.png", "skybox.png") == 0          # dispatch.java:221-222: the sky is texture 0
+    sc.addMaterial("default")
+    sc.addObject(d, 0)                                          # a directory: every .mtl, then every .obj (case-insensitive)
+    names = [n for _, n in sc.textures()]
+    assert names == ["skybox.png", "tex\\wood.png", "tex\\bump.png", "tex\\rough.png"]      # '/' -> '\\' (:1330); deduplicated by name
+    assert [p for p, _ in sc.textures()][1] == d + "/tex/wood.png"
+    b = sc.pack()
+    assert b[14][0] == 48
+    m = b[14][1:].reshape(-1, 48)
+    assert m.shape[0] == 3
+    wood, lamp = m[1], m[2]
+    np.testing.assert_array_equal(wood[0:9], np.float32([0.1, 0.2, 0.3, 0.5, 0.6, 0.7, 0.25, 0.25, 0.25]))
+    assert wood[9] == 96 and wood[10] == np.float32(0.75) and wood[11] == np.float32(0.25) and wood[15] == np.float32(1.45)   # d sets Tr = 1 - d
+    assert wood[19] == 1 and wood[20] == 2                      # Density default, illum
+    assert wood[22] == 1 and wood[36] == 2 and wood[21] == -1   # map_Kd, map_bump, map_Ka
+    assert wood[25] == np.float32(0.4)
+    np.testing.assert_array_equal(wood[42:45], np.float32([1, 0.5, 0.25]))
+    assert lamp[19] == 5 and lamp[11] == np.float32(0.25) and lamp[10] == np.float32(0.75)     # Density = |Ke|; Tr sets d
+    assert lamp[40] == 1 and lamp[32] == 3                      # map_Ke reuses wood.png by name; refl -> map_Pr
+    t = b[3].reshape(-1, 40)
+    assert t.shape[0] == 4 and list(t[:, 36]) == [1, 1, 2, 2]   # usemtl resolves <name><dir> (:924, :1328)
+    tex = sc.load_textures()
+    assert sorted(tex) == [1, 2, 3] and tex[1].shape == (6, 5, 4) and (tex[1][..., 3] == 255).all()
+    assert (tex[3][..., 0] == tex[3][..., 1]).all()             # grey -> RGBA like stbi_load(..., 4)
+
+
+def test_parse_mtls_errors(pt, tmp_path):
+    d = _asset_dir(tmp_path)
+    sc = pt.hostlib.Scene()
+    with pytest.raises(RuntimeError, match="cannot open MTL"):
+        sc.parseMtls(d + "/nope.mtl", d)
+    (tmp_path / "bad.mtl").write_text("newmtl x\nmap_Kd missing.png\n")
+    with pytest.raises(RuntimeError, match="cannot read texture"):
+        sc.parseMtls(str(tmp_path / "bad.mtl"), str(tmp_path))
+    (tmp_path / "bad2.mtl").write_text("newmtl x\nKd 0.5  0.5 0.5\n")       # double space: split(" ") yields an empty token
+    with pytest.raises(RuntimeError, match="NumberFormatException"):
+        sc.parseMtls(str(tmp_path / "bad2.mtl"), str(tmp_path))
+    empty = tmp_path / "empty"; empty.mkdir()
+    with pytest.raises(RuntimeError, match="no obj files"):
+        sc.addObject(str(empty), 0)
