@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--path-slots", type=int, default=None)
+    ap.add_argument("--max-batch", type=int, default=32, help="frames per wavefront batch (bounds the per-frame staging buffer: 16 B x pixels x frames)")
     ap.add_argument("--lds-budget", type=int, default=None)
     ap.add_argument("--extend-mode", type=int, default=None)
     ap.add_argument("--extend-tpb", type=int, default=None)
@@ -48,7 +49,6 @@ def main():
     ap.add_argument("--refill-min", type=int, default=None)
     ap.add_argument("--extend-blocks-per-cu", type=int, default=None)
     ap.add_argument("--inner-keep", type=int, default=None)
-    ap.add_argument("--dual-pool", type=int, default=None)
     ap.add_argument("--rehearse-shard", type=int, nargs=2, metavar=("RANK", "COUNT"), default=None,
                     help="single-process rehearsal of ONE tile shard of a COUNT-GPU run (no collective); reports that shard's rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,7 +84,7 @@ def main():
     if args.lds_budget is not None:
         r.set_option("lds_budget", args.lds_budget)
     for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min),
-                      ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep), ("dual_pool", args.dual_pool)):
+                      ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep)):
         if val is not None:
             r.set_option(name, val)
     stream = torch.cuda.Stream(dev)             # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
@@ -99,7 +99,7 @@ def main():
 
     frame_no = [1]
 
-    MAX_BATCH = 32      # frames per wavefront batch (bounds the per-frame staging buffer: 16 B x pixels x frames)
+    MAX_BATCH = args.max_batch
 
     def step():
         done = 0

@@ -108,11 +108,10 @@ int pt_unshard(pt_ctx* ctx, const void* gathered_dev, void* full_dev);
 int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 
 /* Tuning knobs: 0 = path slots in flight (default 0 = automatic: jobs/5 clamped to [2^20, 2^22]), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the
- * simple intersect kernel, 3 = compact the live-slot queue below this %% of live lanes, 4 = intersect kernel (0 simple, 1 persistent),
+ * simple intersect kernel, 3 = retired (accepted, ignored: the batch tail is packed on the device), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on resident persistent blocks per CU (default 3; 0 = as many as LDS allows),
- * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6),
- * 10 = run a batch as two half-pools on two streams so that shading overlaps intersection (default 0: measured slower) */
+ * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 
 /* Statistics since the last pt_reset_counters (PT_CNT_* order).  Node/triangle/hit-update counts

@@ -42,20 +42,26 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
     } while (0)
 
 constexpr int BLOCK = 256;
+#ifndef SHADE_BLOCK_SIZE
+#define SHADE_BLOCK_SIZE 256
+#endif
+constexpr int SHADE_BLOCK = SHADE_BLOCK_SIZE;     // threads per block of the shading kernel: one scheduler atomic per block per launch
 constexpr int TILE_W = 32, TILE_H = 8;
 
 struct FrameIn { float params[12]; float origin[3]; float rotation[3]; float mouse[3]; };
 
 struct Control {            // device-resident scheduler words shared by the whole batch
     unsigned nextJob;       // next unassigned job
+    // exhausted[(j+1)&3] is raised by the shading launch of iteration j when a job pull comes back empty (sticky).  A word is
+    // written by iteration j-1 and read by iterations j and j+1 only, so every launch sees stable values:
+    //   shading of iteration j writes the dense queue of surviving slots iff exhausted[j&3];
+    //   iteration j reads its slots through that queue iff exhausted[(j-1)&3].
+    unsigned exhausted[4];
     unsigned pad[3];
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
+    unsigned qCount[64];    // entries of queue (j&1) at [32*(j&1)]: two words, 128 B apart
 };
-struct PoolCtl {            // per path pool (the batch runs as two half-pools on two streams, see renderBatch)
-    int nAlive;             // live path slots of this pool
-    unsigned nQueue;        // compaction output cursor
-    unsigned pad[30];       // one 128-B line per pool
-};
+__device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return ctl->exhausted[(iter + 3) & 3] != 0; }
 
 struct State {              // SoA path pool, float4 groups (see header comment)
     float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *S1, *S2, *H;
@@ -175,12 +181,14 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Batch b, const FrameConst* f
 
 // rayScene for every live path slot.  Dynamic LDS: [nodes 4*ldsNodes float4][tris 3*ldsTris float4][stack depth*BLOCK int]
 template <bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const unsigned* queue, const unsigned* nQueue, int nSlots, Control* ctl) {
+__global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots, Control* ctl) {
     extern __shared__ float4 smem[];
     float4* ldsN = smem;
     float4* ldsT = smem + 4 * sc.ldsNodes;
     int* stkBase = reinterpret_cast<int*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris);
-    unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    const unsigned* queue = queueIn(ctl, iter) ? qIn : nullptr;
+    unsigned n = queue ? ctl->qCount[32 * (iter & 1)] : (unsigned)nSlots;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->qCount[32 * ((iter + 1) & 1)] = 0;     // cursor of the queue this iteration's shading may write
     if (blockIdx.x * BLOCK >= n) return;                       // whole block beyond the live range
     for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += BLOCK) ldsN[k] = sc.nodes[k];
     for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += BLOCK) ldsT[k] = sc.tris[k];
@@ -223,7 +231,7 @@ constexpr int CUR_NONE = 0x7ffffffe;
 constexpr int CUR_IDLE = 0x7fffffff;
 
 template <bool COUNT, typename StackT, int TPB>
-__global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* queue, const unsigned* nQueue, int nSlots,
+__global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
                                                        Control* ctl, int refillMin, int keepEighths, int nObjLds) {
     extern __shared__ float4 smem[];
     float4* ldsN = smem;
@@ -235,7 +243,9 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += TPB) ldsN[k] = sc.nodes[k];
     for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += TPB) ldsT[k] = sc.tris[k];
     __syncthreads();
-    const unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    const unsigned* queue = queueIn(ctl, iter) ? qIn : nullptr;
+    const unsigned n = queue ? ctl->qCount[32 * (iter & 1)] : (unsigned)nSlots;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->qCount[32 * ((iter + 1) & 1)] = 0;     // cursor of the queue this iteration's shading may write
     const int lane = threadIdx.x & 63;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const unsigned nWaves = gridDim.x * (TPB / 64), waveId = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
@@ -389,18 +399,22 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
 // that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes all parked
 // rays densely after a barrier.
 template <bool TRANS, bool STATS, bool DIRECT, bool TEX>
-__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* queue, const unsigned* nQueue,
-                                                 int nSlots, Control* ctl, PoolCtl* pc) {
-    __shared__ unsigned sPerm[BLOCK], sFlags[BLOCK];
-    __shared__ uint4 sRegen[BLOCK];
-    __shared__ unsigned sCntA[BLOCK / 64], sCntB[BLOCK / 64], sBase, sRegenCount;
+__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
+                                                 int nSlots, Control* ctl) {
+    __shared__ unsigned sPerm[SHADE_BLOCK], sFlags[SHADE_BLOCK];
+    __shared__ uint4 sRegen[SHADE_BLOCK];
+    __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase, sRegenCount;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const FrameConst& fc = *fcp;
-    const unsigned n = queue ? *nQueue : (unsigned)nSlots;
+    const unsigned* queue = queueIn(ctl, iter) ? qIn : nullptr;
+    const unsigned n = queue ? ctl->qCount[32 * (iter & 1)] : (unsigned)nSlots;
+    const bool writeQueue = ctl->exhausted[iter & 3] != 0;        // job supply ran dry before this iteration: pack the survivors
+    if (writeQueue && blockIdx.x == 0 && threadIdx.x == 0) ctl->exhausted[(iter + 1) & 3] = 1u;     // sticky, also through an empty launch
+    if (blockIdx.x * SHADE_BLOCK >= n) return;                           // the grid is sized by the host's last known bound
     // ---- 1. classify own slot, 2. block-level partition
     {
-        unsigned q = blockIdx.x * BLOCK + threadIdx.x;
+        unsigned q = blockIdx.x * SHADE_BLOCK + threadIdx.x;
         bool valid = q < n;
         unsigned i = valid ? (queue ? queue[q] : q) : 0;
         const unsigned fl = valid ? __float_as_uint(st.G1[i].w) : 0u;
@@ -414,7 +428,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         __syncthreads();
         unsigned nHit = 0, hBefore = 0, mBefore = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) { nHit += sCntA[w]; if (w < wave) { hBefore += sCntA[w]; mBefore += sCntB[w]; } }
+        for (int w = 0; w < SHADE_BLOCK / 64; w++) { nHit += sCntA[w]; if (w < wave) { hBefore += sCntA[w]; mBefore += sCntB[w]; } }
         sPerm[threadIdx.x] = 0xffffffffu;
         __syncthreads();
         if (isHit) { unsigned k = hBefore + (unsigned)__popcll(mh & ltMask); sPerm[k] = i; sFlags[k] = fl; }
@@ -475,20 +489,39 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
     if (threadIdx.x == 0) {
         unsigned total = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) total += sCntA[w];
-        sBase = total ? atomicAdd(&ctl->nextJob, total) : 0u;
+        for (int w = 0; w < SHADE_BLOCK / 64; w++) total += sCntA[w];
+        sBase = total ? (writeQueue ? b.nJobs : atomicAdd(&ctl->nextJob, total)) : 0u;      // known dry: no need to ask
+        if (total && sBase + total > b.nJobs) ctl->exhausted[(iter + 1) & 3] = 1u;                      // an empty pull: the tail begins
     }
     __syncthreads();
     if (jobDone) {
         unsigned off = 0;
 #pragma unroll
-        for (int w = 0; w < BLOCK / 64; w++) off += (w < wave) ? sCntA[w] : 0u;
+        for (int w = 0; w < SHADE_BLOCK / 64; w++) off += (w < wave) ? sCntA[w] : 0u;
         unsigned job = sBase + off + (unsigned)__popcll(mask & ltMask);
         if (job < b.nJobs) { startJob(b, fc, job, p); needStart = true; newJob = true; }
         else p.alive = false;
     }
-    unsigned long long dead = __ballot(jobDone && !p.alive);
-    if (dead && lane == (__ffsll((long long)dead) - 1)) atomicAdd(&pc->nAlive, -(int)__popcll(dead));
+    // ---- 4b. tail of the batch: the slots that stay alive go into the next iteration's dense queue (one atomic per block)
+    if (writeQueue) {
+        const bool keep = live && p.alive;
+        unsigned long long mk = __ballot(keep);
+        if (lane == 0) sCntB[wave] = (unsigned)__popcll(mk);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned total = 0;
+#pragma unroll
+            for (int w = 0; w < SHADE_BLOCK / 64; w++) total += sCntB[w];
+            sBase = total ? atomicAdd(&ctl->qCount[32 * ((iter + 1) & 1)], total) : 0u;
+        }
+        __syncthreads();
+        if (keep) {
+            unsigned off = 0;
+#pragma unroll
+            for (int w = 0; w < SHADE_BLOCK / 64; w++) off += (w < wave) ? sCntB[w] : 0u;
+            qOut[sBase + off + (unsigned)__popcll(mk & ltMask)] = i;
+        }
+    }
     // ---- 5. store; lanes that start a sample do the prologue themselves and park the camera ray for the dense pass
     if (needStart) tracePrologue(p);
     unsigned long long ms = __ballot(needStart);
@@ -522,7 +555,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
     __syncthreads();
     // ---- 6. dense camera-ray pass (frag.glsl:899-908): overwrites O, D, rngState of the parked slots
     const unsigned nRegen = sRegenCount;
-    for (unsigned k = threadIdx.x; k < nRegen; k += BLOCK) {
+    for (unsigned k = threadIdx.x; k < nRegen; k += SHADE_BLOCK) {
         uint4 e = sRegen[k];
         uint32_t rng = e.y;
         vec3 O, D;
@@ -530,23 +563,6 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Batch b, const Fra
         st.G0[e.x] = make_float4(O.x, O.y, O.z, D.x);
         st.G1[e.x] = make_float4(D.y, D.z, __uint_as_float(rng), __uint_as_float(e.w));
     }
-}
-
-// wave64 ballot + prefix-sum (mbcnt) stream compaction of live slot indices: one atomic per wave
-__global__ void __launch_bounds__(BLOCK) k_compact(State st, const unsigned* inQueue, const unsigned* nIn, int nSlots, unsigned* outQueue, PoolCtl* pc) {
-    unsigned n = inQueue ? *nIn : (unsigned)nSlots;
-    unsigned q = blockIdx.x * BLOCK + threadIdx.x;
-    bool valid = q < n;
-    unsigned i = valid ? (inQueue ? inQueue[q] : q) : 0;
-    bool live = valid && (__float_as_uint(st.G1[i].w) & FL_ALIVE);
-    unsigned long long mask = __ballot(live);
-    if (!mask) return;
-    int lane = threadIdx.x & 63;
-    int leader = __ffsll((long long)mask) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(&pc->nQueue, (unsigned)__popcll(mask));
-    base = __shfl(base, leader);
-    if (live) outQueue[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
 
 // FRAME accumulation, frag.glsl:924-933, over this batch's frames in u_frameCount order
@@ -596,12 +612,11 @@ __global__ void k_unshard(const float4* gathered, const int* maps, int nSlots, i
     if (gp >= 0) full[gp] = gathered[k];
 }
 
-__global__ void k_init_control(Control* ctl, unsigned nextJob, PoolCtl* pools, int alive0, int alive1) {
+__global__ void k_init_control(Control* ctl, unsigned nextJob) {
     ctl->nextJob = nextJob;
-    pools[0].nAlive = alive0; pools[0].nQueue = 0; pools[1].nAlive = alive1; pools[1].nQueue = 0;
+    for (int k = 0; k < 4; k++) ctl->exhausted[k] = 0;
+    ctl->qCount[0] = 0; ctl->qCount[32] = 0;
 }
-__global__ void k_zero_queue_cursor(PoolCtl* pc) { pc->nQueue = 0; }
-__global__ void k_copy_queue_count(const PoolCtl* pc, unsigned* nQueueOut) { *nQueueOut = pc->nQueue; }
 
 __global__ void k_debug_math(int fn, const float* x, const float* y, float* out, size_t n) {
     size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -647,12 +662,11 @@ struct pt_ctx {
     int poolSlots = 0;              // 0 = automatic: jobs/5 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
     int poolActive = 0; int allocSlots = 0; bool allocTrans = false;
     State st{};
-    unsigned *dQueueA = nullptr, *dQueueB = nullptr, *dNQueue = nullptr;
+    unsigned* dQueue[2] = {nullptr, nullptr};      // dense slot queues of the batch tail, by iteration parity
     float4* dColbuf = nullptr; size_t colbufElems = 0;
     int* dSeeds = nullptr; int seedsCap = 0;
-    FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr; PoolCtl* dPool = nullptr;
-    hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; std::vector<hipEvent_t> evRing; bool dualPool = false;
-    int* hAlive = nullptr;          // pinned, one int per pool
+    FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
+    Control* hCtl = nullptr;        // pinned copy for the host's polls
     FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr; int hSeedsCap = 0;   // pinned staging
     // options / stats
     bool countStats = false, timing = false;
@@ -660,7 +674,6 @@ struct pt_ctx {
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
     int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
     bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 3; int innerKeepEighths = 6;
-    int compactBelowPct = 70;       // compact the queue when fewer than this % of the launched lanes are live
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
 };
@@ -889,15 +902,15 @@ int ensurePool(pt_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H};
     for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
-    for (unsigned** q : {&c->dQueueA, &c->dQueueB}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
+    for (unsigned** q : {&c->dQueue[0], &c->dQueue[1]}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     size_t n = (size_t)c->poolActive;
     for (int k = 0; k < 10; k++) {
         bool transOnly = (k >= 5 && k <= 8);
         if (transOnly && !c->trans) continue;
         HIP_TRY(hipMalloc((void**)groups[k], n * 16));
     }
-    HIP_TRY(hipMalloc((void**)&c->dQueueA, n * 4));
-    HIP_TRY(hipMalloc((void**)&c->dQueueB, n * 4));
+    HIP_TRY(hipMalloc((void**)&c->dQueue[0], n * 4));
+    HIP_TRY(hipMalloc((void**)&c->dQueue[1], n * 4));
     c->allocSlots = c->poolActive; c->allocTrans = c->trans;
     return 0;
 }
@@ -919,13 +932,13 @@ int nextEventPair(pt_ctx::KT& k) {
     } while (0)
 #define TIMED_LAUNCH(kidx, ...) TIMED_LAUNCH_ON(s, kidx, __VA_ARGS__)
 
-struct PoolRun {            // host view of one path pool while a batch runs
-    hipStream_t stream; State st; PoolCtl* pc; unsigned* dNQueue; unsigned *qCur, *qNext; const unsigned* queue; unsigned launched; int alive; int* hAlive;
+struct PoolRun {            // host view of the path pool while a batch runs
+    hipStream_t stream; State st; unsigned launched; int iter;      // launched: the host's upper bound on the slots an iteration visits
 };
 template <bool COUNT, typename StackT, int TPB>
 void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int grid) {
     int nObjLds = std::min(sc.numObj, 8);
-    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl, c->refillMin,
+    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
                        c->innerKeepEighths, nObjLds);
 }
 void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
@@ -1001,102 +1014,57 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
     } else { b.divM = 0; b.divS = 0; }
     int N = c->poolActive;
     unsigned first = (unsigned)std::min<size_t>((size_t)N, nJobs64);
-    // Optional (pt_set_option 10, default off): two half-pools on two streams, so that the HBM-bound shading of one half
-    // runs underneath the VALU-bound intersection of the other; cross-stream events chain the intersect launches
-    // (E_A1 -> E_B1 -> E_A2 -> ...) so that two of them never share the machine.  Measured on C3: 812 vs 1210 Msamples/s —
-    // the shading kernel's HBM traffic stretches the intersect kernel's memory latency far more than the overlap gains
-    // (profiles/), so batches run as ONE pool on one stream.
-    const bool dual = c->dualPool && first >= (unsigned)(1 << 19);
-    const unsigned half = dual ? (unsigned)(((size_t)N / 2 + BLOCK - 1) / BLOCK * BLOCK) : (unsigned)N;
-    auto offsetState = [](State st, size_t off) {
-        State o = st;
-        o.G0 += off; o.G1 += off; o.G2 += off; o.G3 += off; o.G4 += off; o.H += off;
-        if (o.G5) { o.G5 += off; o.S0 += off; o.S1 += off; o.S2 += off; }
-        return o;
-    };
-    PoolRun pools[2];
-    const int nPools = dual ? 2 : 1;
-    for (int pi = 0; pi < nPools; pi++) {
-        PoolRun& pr = pools[pi];
-        size_t off = (size_t)pi * half;
-        pr.stream = pi ? c->sideStream : s;
-        pr.st = offsetState(c->st, off);
-        pr.pc = c->dPool + pi; pr.dNQueue = c->dNQueue + pi; pr.hAlive = c->hAlive + pi;
-        pr.qCur = c->dQueueA + off; pr.qNext = c->dQueueB + off; pr.queue = nullptr;
-        unsigned lo = (unsigned)std::min<size_t>(off, first), hi = (unsigned)std::min<size_t>(off + (pi == nPools - 1 ? (size_t)N : half), first);
-        pr.launched = hi - lo; pr.alive = (int)(hi - lo);
-    }
-    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first, c->dPool, pools[0].alive, dual ? pools[1].alive : 0);
+    // One pool on one stream.  (Two half-pools on two streams, shading one half underneath the intersection of the other, were
+    // measured on C3 at 812 vs 1210 Msamples/s: the shading kernel's HBM traffic stretches the intersect kernel's memory latency
+    // far more than the overlap gains — DESIGN.md "rejected".)
+    PoolRun pr;
+    pr.stream = s; pr.st = c->st; pr.launched = first; pr.iter = 0;
+    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first);
     int gridN = (N + BLOCK - 1) / BLOCK;
     if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<true>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
     else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<false>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
-    if (dual) { HIP_TRY(hipEventRecord(c->evFork, s)); HIP_TRY(hipStreamWaitEvent(c->sideStream, c->evFork, 0)); }
 
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
-    uint64_t iters = 0;
-    int CHECK = 8;
     // every job retires within SAMPLE_RES * ceil(MAX_BOUNCES) iterations of being started, and a slot runs at most
     // ceil(jobs / slots) jobs back to back: a batch that exceeds this bound (x2) is a scheduler bug, not work
     const uint64_t maxIters = 2 * ((nJobs64 + first - 1) / first + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
-    hipEvent_t lastExtend = nullptr; hipStream_t lastExtendStream = nullptr;
-    size_t ring = 0;
-    auto anyAlive = [&]() { for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0) return true; return false; };
-    // Host polls of the live count drain the stream: while no slot has died yet the end is at least one whole job away
-    // (>= SAMPLE_RES iterations), so the steady state is polled every 24 iterations and only the tail every 8.
-    while (anyAlive()) {
-        if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        {
-            bool allFull = true;
-            for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0 && (unsigned)pools[pi].alive < pools[pi].launched) allFull = false;
-            CHECK = (allFull && nJobs64 > first) ? 24 : 8;
-        }
+    // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
+    // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
+    // The host only polls: while jobs remain the end is at least one whole job (>= SAMPLE_RES iterations) away, so it looks
+    // every 24 iterations, in the tail every 8; each look shrinks the launch grids to the live count and ends the batch at 0.
+    bool draining = false, done = false;
+    while (!done) {
+        if ((uint64_t)pr.iter > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
+        const int CHECK = draining ? 8 : 24;
         for (int k = 0; k < CHECK; k++) {
-            for (int pi = 0; pi < nPools; pi++) {
-                PoolRun& pr = pools[pi];
-                if (pr.alive <= 0) continue;
-                hipStream_t ps = pr.stream;
-                int grid = (int)((pr.launched + BLOCK - 1) / BLOCK);
-                if (dual && lastExtend && lastExtendStream != ps) HIP_TRY(hipStreamWaitEvent(ps, lastExtend, 0));
-                if (c->extendMode == 0) {
-                    if (c->countStats) TIMED_LAUNCH_ON(ps, 0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, ps, c->sc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl));
-                    else TIMED_LAUNCH_ON(ps, 0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, ps, c->sc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl));
-                } else {
-                    TIMED_LAUNCH_ON(ps, 0, launchExtendPersist(c, pr));
-                }
-                if (dual) {
-                    lastExtend = c->evRing[ring++ % c->evRing.size()]; lastExtendStream = ps;
-                    HIP_TRY(hipEventRecord(lastExtend, ps));
-                }
-#define SHADE_ARGS dim3(grid), dim3(BLOCK), 0, ps, c->sc, b, c->dFc, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, c->dCtl, pr.pc
-                // kernel variant: transmissive materials present / statistics on / RAYTRACING == 0 / texture-mapped materials present
-#define SHADE_V(T, S, D, X) TIMED_LAUNCH_ON(ps, 1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
+            const int grid = std::max(1, (int)((pr.launched + BLOCK - 1) / BLOCK));
+            if (c->extendMode == 0) {
+                if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
+                else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
+            } else {
+                TIMED_LAUNCH(0, launchExtendPersist(c, pr));
+            }
+#define SHADE_ARGS dim3(std::max(1, (int)((pr.launched + SHADE_BLOCK - 1) / SHADE_BLOCK))), dim3(SHADE_BLOCK), 0, s, c->sc, b, c->dFc, pr.st, c->dQueue[pr.iter & 1], c->dQueue[(pr.iter + 1) & 1], pr.iter, (int)pr.launched, c->dCtl
+            // kernel variant: transmissive materials present / statistics on / RAYTRACING == 0 / texture-mapped materials present
+#define SHADE_V(T, S, D, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
 #define SHADE_S(T, D, X) do { if (c->countStats) SHADE_V(T, true, D, X); else SHADE_V(T, false, D, X); } while (0)
 #define SHADE_X(T, D) do { if (c->anyMaps) SHADE_S(T, D, true); else SHADE_S(T, D, false); } while (0)
-                if (direct) SHADE_X(false, true);
-                else if (c->trans) SHADE_X(true, false);
-                else SHADE_X(false, false);
-            }
-            iters++;
+            if (direct) SHADE_X(false, true);
+            else if (c->trans) SHADE_X(true, false);
+            else SHADE_X(false, false);
+            pr.iter++;
         }
-        for (int pi = 0; pi < nPools; pi++) if (pools[pi].alive > 0) HIP_TRY(hipMemcpyAsync(pools[pi].hAlive, &pools[pi].pc->nAlive, 4, hipMemcpyDeviceToHost, pools[pi].stream));
-        for (int pi = 0; pi < nPools; pi++) HIP_TRY(hipStreamSynchronize(pools[pi].stream));
-        lastExtend = nullptr;
-        for (int pi = 0; pi < nPools; pi++) {
-            PoolRun& pr = pools[pi];
-            if (pr.alive <= 0) continue;
-            pr.alive = *pr.hAlive;
-            // tail: once job supply has run dry the pool thins out -> compact live slots into a dense queue
-            if (pr.alive > 0 && (uint64_t)pr.alive * 100 < (uint64_t)pr.launched * (uint64_t)c->compactBelowPct) {
-                int grid = (int)((pr.launched + BLOCK - 1) / BLOCK);
-                hipLaunchKernelGGL(k_zero_queue_cursor, dim3(1), dim3(1), 0, pr.stream, pr.pc);
-                hipLaunchKernelGGL(k_compact, dim3(grid), dim3(BLOCK), 0, pr.stream, pr.st, pr.queue, pr.dNQueue, (int)pr.launched, pr.qNext, pr.pc);
-                hipLaunchKernelGGL(k_copy_queue_count, dim3(1), dim3(1), 0, pr.stream, pr.pc, pr.dNQueue);
-                pr.queue = pr.qNext; std::swap(pr.qCur, pr.qNext);
-                pr.launched = (unsigned)pr.alive;      // k_compact wrote exactly `alive` entries
-            }
+        HIP_TRY(hipMemcpyAsync(c->hCtl, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (c->hCtl->exhausted[(pr.iter + 3) & 3]) {              // iteration pr.iter reads the queue: its count is exact
+            draining = true;
+            pr.launched = c->hCtl->qCount[32 * (pr.iter & 1)];
+            done = pr.launched == 0;
+        } else if (c->hCtl->nextJob >= b.nJobs) {
+            draining = true;                                       // jobs just ran out; the queue starts within two iterations
         }
     }
-    if (dual) { HIP_TRY(hipEventRecord(c->evJoin, c->sideStream)); HIP_TRY(hipStreamWaitEvent(s, c->evJoin, 0)); }
+    const uint64_t iters = (uint64_t)pr.iter;
     int gridA = (c->nSlotsImg + BLOCK - 1) / BLOCK;
     TIMED_LAUNCH(3, hipLaunchKernelGGL(k_accumulate, dim3(gridA), dim3(BLOCK), 0, s, b, c->dFc, c->dFrame));
     HIP_TRY(hipGetLastError());
@@ -1157,15 +1125,7 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
     HIP_TRY(hipMalloc((void**)&c->dFc, sizeof(FrameConst)));
     HIP_TRY(hipMalloc((void**)&c->dCtl, sizeof(Control)));
     HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
-    HIP_TRY(hipMalloc((void**)&c->dNQueue, 8));
-    HIP_TRY(hipMalloc((void**)&c->dPool, 2 * sizeof(PoolCtl)));
-    HIP_TRY(hipMemset(c->dPool, 0, 2 * sizeof(PoolCtl)));
-    HIP_TRY(hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming));
-    c->evRing.resize(64);
-    for (auto& e : c->evRing) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void**)&c->hAlive, 8, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->hCtl, sizeof(Control), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->hFrameIn, sizeof(FrameIn), hipHostMallocDefault));
     c->imp = {0.0f}; c->ellip = {0.0f}; c->objidx = {0};
     c->mouse = {-1.0e6f, -1.0e6f, 0.0f};
@@ -1179,16 +1139,12 @@ int pt_destroy(pt_ctx* c) {
     hipStreamSynchronize(c->stream);
     for (float4* p : c->dTexData) if (p) hipFree(p);
     void* ptrs[] = {c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
-                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueueA, c->dQueueB, c->dNQueue, c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dPool};
+                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl};
     for (void* p : ptrs) if (p) hipFree(p);
-    if (c->hAlive) hipHostFree(c->hAlive);
+    if (c->hCtl) hipHostFree(c->hCtl);
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
     if (c->hSeeds) hipHostFree(c->hSeeds);
     for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (auto& e : c->evRing) hipEventDestroy(e);
-    if (c->evFork) hipEventDestroy(c->evFork);
-    if (c->evJoin) hipEventDestroy(c->evJoin);
-    if (c->sideStream) { hipStreamSynchronize(c->sideStream); hipStreamDestroy(c->sideStream); }
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return PT_OK;
@@ -1323,13 +1279,12 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 0: if (value != 0 && (value < BLOCK || value > (1 << 26))) return fail(PT_ERR_ARG, "path slots must be 0 (automatic) or in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
         case 1: c->countStats = value != 0; return PT_OK;
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
-        case 3: c->compactBelowPct = (int)value; return PT_OK;
+        case 3: return PT_OK;      // (was: host-side compaction threshold; the tail is packed on the device now) accepted, ignored
         case 4: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "extend mode must be 0 or 1"); c->extendMode = (int)value; return PT_OK;
         case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
         case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
-        case 10: c->dualPool = value != 0; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");
@@ -1419,7 +1374,8 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     HIP_TRY(hipMemcpy(c->dFrameIn, &fin, sizeof(fin), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, c->stream, c->sc, c->dFrameIn, c->dFc, c->dEllip);
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
-    hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, c->dNQueue, (int)np, c->dCtl);
+    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, c->stream, c->dCtl, 0u);
+    hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, 0, (int)np, c->dCtl);
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> h(np * 4);
     HIP_TRY(hipMemcpy(h.data(), st.H, np * 16, hipMemcpyDeviceToHost));

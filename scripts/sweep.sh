@@ -1,15 +1,11 @@
 #!/bin/bash
+# one-GPU rehearsal sweeps of a single shard (bench.py --rehearse-shard): prints value and ms/step per option set
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-run() { python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --rehearse-shard 0 8 "$@" 2>/dev/null | python3 -c "
+SH=${SHARD:-"0 8"}
+run() { timeout -k 10 120 python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --rehearse-shard $SH "$@" 2>/dev/null | python3 -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('$*', '->', d['value'], 'Ms/s  ms/step', d['ms_per_step'])
+        d=json.loads(l); print('$SH | $*', '->', d['value'], 'Ms/s  ms/step', d['ms_per_step'])
 "; }
-run
-run --simple-below 65536
-run --simple-below 262144
-run --simple-below 786432
-run --extend-cache 0
-run --extend-cache 4096
-run
+for a in "$@"; do run $a; done

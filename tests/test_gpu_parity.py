@@ -112,10 +112,11 @@ def test_render_parity_persistent_variants(pt, oracle, renderer_mod, tpb, cache,
     assert_same(got, ref, cnt, ocnt)
 
 
-def test_render_parity_small_pool_and_compaction(pt, oracle, renderer_mod):
-    """pool much smaller than the job count: exercises regeneration, job pulling and the compacted tail"""
+@pytest.mark.parametrize("slots,extend_mode", [(2048, 1), (256, 1), (9216, 0), (1 << 16, 1)])
+def test_render_parity_small_pool_and_packed_tail(pt, oracle, renderer_mod, slots, extend_mode):
+    """pool smaller than (or larger than) the job count: regeneration, job pulling, the hand-over to the device-packed tail queue"""
     wl = pt.scenes.build("C3", 128, 72)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 4, path_slots=2048, compact_below_pct=95)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 4, path_slots=slots, extend_mode=extend_mode)
     assert_same(got, ref, cnt, ocnt)
 
 
@@ -233,12 +234,6 @@ def test_full_size_properties_c3(pt, oracle, renderer_mod):
     for i, s in enumerate(seeds):
         oracle.render(sc, W, H, 1 + i, s, ref, nthreads=8, xs=24, ys=27)
     assert np.array_equal(a[::27, ::24], ref[::27, ::24])
-    # the optional two-half-pools-on-two-streams schedule renders the same bits
-    r = renderer_mod.Renderer(W, H)
-    r.set_option("dual_pool", 1)
-    r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds)
-    assert np.array_equal(r.read_frame(), a)
-    r.close()
 
 
 def test_two_process_shards_on_one_gpu(pt):
