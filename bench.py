@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--path-slots", type=int, default=None)
+    ap.add_argument("--sync", action="store_true", help="drain the path pool at the end of every step (pt_render_batch) instead of overlapping consecutive steps")
     ap.add_argument("--max-batch", type=int, default=32, help="frames per wavefront batch (bounds the per-frame staging buffer: 16 B x pixels x frames)")
     ap.add_argument("--lds-budget", type=int, default=None)
     ap.add_argument("--extend-mode", type=int, default=None)
@@ -92,26 +93,54 @@ def main():
     r.set_stream(stream.cuda_stream)
     r.load_workload(wl)
     r.reset_frame()
-    packed = shard.frame_tensor(r, dev)
     unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev) if not args.rehearse_shard else (lambda t: t)
     if args.rehearse_shard:
         unshard.world = 1
 
-    frame_no = [1]
-
     MAX_BATCH = args.max_batch
 
+    # One step = one image: reset, spp_step samples per pixel, ONE framebuffer gather.  Consecutive steps overlap on the GPU:
+    # a step's last paths finish underneath the next step's first ones (pt_render_batch_async / pt_next_image), and its
+    # image is gathered while the next one renders.  Every step's work and gather lie inside the timed region; the fence
+    # completes everything that is still in flight.
+    LAG = 2                     # an image is gathered two steps after it was submitted: by then its last paths have long retired
+    in_flight = [0]
+
     def step():
+        out = None
+        if args.sync:
+            r.reset_frame()
+        else:
+            r.next_image()
         done = 0
         while done < fps:
             n = min(MAX_BATCH, fps - done)
-            first = frame_no[0]
-            r.render_batch(first, [scenes.frame_seed(f) for f in range(first, first + n)])
-            frame_no[0] += n
+            first = 1 + done
+            seeds = [scenes.frame_seed(f) for f in range(first, first + n)]
+            if args.sync:
+                r.render_batch(first, seeds)
+            else:
+                r.render_batch_async(first, seeds)
             done += n
-        return shard.gather_frame(packed, unshard, dst=0)
+        if args.sync:
+            return shard.gather_frame(shard.frame_tensor(r, dev), unshard, dst=0)
+        if in_flight[0] == LAG:
+            r.finish_image(LAG)
+            out = shard.gather_frame(shard.frame_tensor(r, dev, age=LAG), unshard, dst=0)
+        else:
+            in_flight[0] += 1
+        return out
+
+    def drain():
+        out = None
+        while in_flight[0] > 0:
+            in_flight[0] -= 1
+            r.finish_image(in_flight[0])
+            out = shard.gather_frame(shard.frame_tensor(r, dev, age=in_flight[0]), unshard, dst=0)
+        return out
 
     def fence():
+        r.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -131,6 +160,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     fence()
     r.reset_counters()
     if not args.no_roofline:
@@ -139,6 +169,7 @@ def main():
     full = None
     for _ in range(args.steps):
         full = step()
+    full = drain() if not args.sync else full
     fence()
     dt = time.perf_counter() - t0
     r.set_timing(False)

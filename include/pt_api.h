@@ -77,6 +77,23 @@ int pt_render(pt_ctx* ctx, int frame_count, int seed);
  * is bit-identical to n_frames pt_render calls.  Camera/params must not change inside a batch. */
 int pt_render_batch(pt_ctx* ctx, int first_frame, int n_frames, const int32_t* seeds);
 
+/* ---- overlapped batches (no reference counterpart: the GL driver pipelines the reference's draw calls by itself) ----
+ * pt_render_batch_async submits a batch like pt_render_batch but returns once most of its pixel-frame jobs have been handed
+ * to path slots; the rest, and the paths still in flight, finish underneath the next batch, so the path pool never drains
+ * between batches.  Batches overlap as long as the frame inputs (bindings 0, 1, 2, 4) and the scene are unchanged; a change
+ * finishes the running work first.  Frames are still added to the FRAME image in u_frameCount order, bit-identical to the
+ * synchronous calls.  Every other entry point that reads or modifies results (pt_read_frame, pt_read_display,
+ * pt_synchronize, pt_reset_frame, pt_get_counters, pt_set_option, ...) completes all submitted batches first. */
+int pt_render_batch_async(pt_ctx* ctx, int first_frame, int n_frames, const int32_t* seeds);
+/* Start a new, zeroed FRAME image for the batches submitted from now on (a ring of four images); batches already submitted
+ * still land in the image they were submitted for.  The asynchronous counterpart of pt_reset_frame. */
+int pt_next_image(pt_ctx* ctx);
+/* Complete (stream-ordered) every batch submitted for the FRAME image `age` pt_next_image calls ago (0 = current, up to 3).
+ * A path lives for up to SAMPLE_RES * MAX_BOUNCES iterations, so an image is cheapest to finish one or two images later. */
+int pt_finish_image(pt_ctx* ctx, int age);
+/* Device pointer of the FRAME image `age` pt_next_image calls ago (0 = current), layout as pt_frame_device. */
+int pt_image_device(pt_ctx* ctx, int age, void** dev_ptr, size_t* n_pixels);
+
 /* glFinish() (dispatch.java:598) */
 int pt_synchronize(pt_ctx* ctx);
 

@@ -23,6 +23,7 @@
 #include "pt_device.hpp"
 
 #include <algorithm>
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -57,7 +58,9 @@ struct Control {            // device-resident scheduler words shared by the who
     //   shading of iteration j writes the dense queue of surviving slots iff exhausted[j&3];
     //   iteration j reads its slots through that queue iff exhausted[(j-1)&3].
     unsigned exhausted[4];
-    unsigned pad[3];
+    unsigned jobEnd;        // jobs submitted to the frame stream so far: ids [0, jobEnd) exist (k_submit)
+    unsigned needRevive;    // k_submit -> k_revive: dead slots may take jobs again
+    unsigned oldestBusy;    // k_scan_inflight: a live slot still works on the oldest unaccumulated batch
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
     unsigned qCount[64];    // entries of queue (j&1) at [32*(j&1)]: two words, 128 B apart
 };
@@ -67,15 +70,17 @@ struct State {              // SoA path pool, float4 groups (see header comment)
     float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *S1, *S2, *H;
 };
 
+// The frame stream: consecutive batches with the same frame inputs (Parameters, ORIGIN, ROTATION, MOUSE_POS) form ONE job
+// sequence, job = streamFrame * nLocal + pixel, so that the path pool never drains between them.  Per-frame data (u_seed,
+// the frame's colour row) live in rings of `ringFrames` rows indexed by streamFrame % ringFrames.
 struct Batch {
     int W, H, nLocal, nSlots, shardCount;
-    unsigned nJobs;
     unsigned divM, divS;      // job / nLocal == mulhi(job, divM) >> divS for job < 2^31 (nLocal >= 2); divM == 0: nLocal == 1
-    int firstFrame, nFrames;
-    const int* seeds;         // device, nFrames
+    unsigned ringFrames;
+    const int* seeds;         // device ring, ringFrames
     const int* pixList;       // device, nLocal: global pixel index in tile-major job order
     const unsigned* pixXY;    // device, nLocal: the same pixels as x | y << 16
-    float4* colbuf;           // nFrames * nSlots
+    float4* colbuf;           // device ring, ringFrames * nSlots
 };
 
 // ------------------------------------------------------------------------------------------------ kernels
@@ -149,7 +154,7 @@ __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, u
     pixelIndex(fc, b.W, b.H, px, py, index);
     p.pix = xy; p.fi = fi;
     p.ls = (b.shardCount == 1) ? (unsigned)(py * b.W + px) : k;
-    p.rng = index + (uint32_t)b.seeds[fi];
+    p.rng = index + (uint32_t)b.seeds[fi % b.ringFrames];
     p.sum = v3(0.0f);
     p.sample = 0;
     p.applyAbs = false; p.inObj = false;
@@ -160,21 +165,46 @@ __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, u
     p.alive = true;
 }
 
+// Every dead slot of the pool asks for a job (one scheduler atomic per block) and, if one is left, starts it: the start of
+// a frame stream (all slots dead) and the restart after the pool ran dry between two batches.
 template <bool TRANS>
-__global__ void __launch_bounds__(BLOCK) k_generate(Batch b, const FrameConst* fcp, State st, int nSlots, Control* ctl) {
+__global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp, State st, int nSlots, Control* ctl) {
+    __shared__ unsigned sCnt[BLOCK / 64], sBase;
+    const unsigned mode = ctl->needRevive;
+    if (!mode) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= (unsigned)nSlots) return;
-    const FrameConst& fc = *fcp;
-    Path p;
-    if (i < b.nJobs) {
+    if (mode == 2u) {                                              // start of a stream: every slot is dead, slot i takes job i
+        if (i >= (unsigned)nSlots || i >= ctl->jobEnd) return;
+        const FrameConst& fc = *fcp;
+        Path p;
         startJob(b, fc, i, p);
         startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
-    } else {
-        p = Path();
-        p.alive = false; p.pix = 0; p.fi = 0; p.ls = 0; p.rng = 0; p.bounce = 0; p.sample = 0; p.stackSize = 0; p.inObj = false; p.applyAbs = false;
-        p.O = p.D = p.col = p.inc = p.sum = p.enter = v3(0.0f); p.dist = 0.0f;
-        for (int k = 0; k < 10; k++) p.s[k] = 0.0f;
+        storePath(st, i, p, TRANS);
+        st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
+        return;
     }
+    const bool want = i < (unsigned)nSlots && !(__float_as_uint(st.G1[i].w) & FL_ALIVE);
+    unsigned long long mask = __ballot(want);
+    if (lane == 0) sCnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; w++) total += sCnt[w];
+        sBase = total ? atomicAdd(&ctl->nextJob, total) : 0u;
+    }
+    __syncthreads();
+    if (!want) return;
+    unsigned off = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; w++) off += (w < wave) ? sCnt[w] : 0u;
+    const unsigned job = sBase + off + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    if (job >= ctl->jobEnd) return;                               // stays dead
+    const FrameConst& fc = *fcp;
+    Path p;
+    startJob(b, fc, job, p);
+    startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
     storePath(st, i, p, TRANS);
     st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
 }
@@ -410,6 +440,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     const unsigned* queue = queueIn(ctl, iter) ? qIn : nullptr;
     const unsigned n = queue ? ctl->qCount[32 * (iter & 1)] : (unsigned)nSlots;
     const bool writeQueue = ctl->exhausted[iter & 3] != 0;        // job supply ran dry before this iteration: pack the survivors
+    const unsigned jobEnd = ctl->jobEnd;
     if (writeQueue && blockIdx.x == 0 && threadIdx.x == 0) ctl->exhausted[(iter + 1) & 3] = 1u;     // sticky, also through an empty launch
     if (blockIdx.x * SHADE_BLOCK >= n) return;                           // the grid is sized by the host's last known bound
     // ---- 1. classify own slot, 2. block-level partition
@@ -476,7 +507,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
                 needStart = true;
             } else {
                 float sr = fc.SAMPLE_RES;
-                b.colbuf[(size_t)p.fi * b.nSlots + p.ls] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
+                b.colbuf[(size_t)(p.fi % b.ringFrames) * b.nSlots + p.ls] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
                 jobDone = true;
             }
         }
@@ -490,8 +521,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         unsigned total = 0;
 #pragma unroll
         for (int w = 0; w < SHADE_BLOCK / 64; w++) total += sCntA[w];
-        sBase = total ? (writeQueue ? b.nJobs : atomicAdd(&ctl->nextJob, total)) : 0u;      // known dry: no need to ask
-        if (total && sBase + total > b.nJobs) ctl->exhausted[(iter + 1) & 3] = 1u;                      // an empty pull: the tail begins
+        sBase = total ? (writeQueue ? jobEnd : atomicAdd(&ctl->nextJob, total)) : 0u;       // known dry: no need to ask
+        if (total && sBase + total > jobEnd) ctl->exhausted[(iter + 1) & 3] = 1u;                      // an empty pull: the tail begins
     }
     __syncthreads();
     if (jobDone) {
@@ -499,7 +530,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
 #pragma unroll
         for (int w = 0; w < SHADE_BLOCK / 64; w++) off += (w < wave) ? sCntA[w] : 0u;
         unsigned job = sBase + off + (unsigned)__popcll(mask & ltMask);
-        if (job < b.nJobs) { startJob(b, fc, job, p); needStart = true; newJob = true; }
+        if (job < jobEnd) { startJob(b, fc, job, p); needStart = true; newJob = true; }
         else p.alive = false;
     }
     // ---- 4b. tail of the batch: the slots that stay alive go into the next iteration's dense queue (one atomic per block)
@@ -565,8 +596,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     }
 }
 
-// FRAME accumulation, frag.glsl:924-933, over this batch's frames in u_frameCount order
-__global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst* fcp, float4* frame) {
+// FRAME accumulation, frag.glsl:924-933, over one batch's frames in u_frameCount order (stream frames f0 .. f0+nFrames-1)
+__global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst* fcp, float4* frame, unsigned f0, int nFrames, int firstFrame) {
     unsigned ls = blockIdx.x * BLOCK + threadIdx.x;
     if (ls >= (unsigned)b.nSlots) return;
     int gp;
@@ -575,12 +606,19 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst*
     const FrameConst& fc = *fcp;
     if (inMouseOverlay(fc, gp % b.W, gp / b.W)) return;
     float4 F = frame[ls];
-    for (int f = 0; f < b.nFrames; f++) {
-        float4 c = b.colbuf[(size_t)f * b.nSlots + ls];
-        if ((float)(b.firstFrame + f) == 1.0f) F = make_float4(c.x, c.y, c.z, 1.0f);
+    for (int f = 0; f < nFrames; f++) {
+        float4 c = b.colbuf[(size_t)((f0 + (unsigned)f) % b.ringFrames) * b.nSlots + ls];
+        if ((float)(firstFrame + f) == 1.0f) F = make_float4(c.x, c.y, c.z, 1.0f);
         else F = make_float4(F.x + c.x, F.y + c.y, F.z + c.z, F.w + 1.0f);
     }
     frame[ls] = F;
+}
+
+// Is any live slot still working on a stream frame below fEnd (the oldest batch that has not been accumulated yet)?
+__global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, unsigned fEnd, Control* ctl) {
+    unsigned i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= (unsigned)nSlots) return;
+    if ((__float_as_uint(st.G1[i].w) & FL_ALIVE) && __float_as_uint(st.G3[i].w) < fEnd) ctl->oldestBusy = 1u;
 }
 
 // fragColor -> UNORM8 framebuffer -> glReadPixels(GL_RGB) -> Java signed-byte packing -> vertical flip (dispatch.java:804-833)
@@ -612,9 +650,20 @@ __global__ void k_unshard(const float4* gathered, const int* maps, int nSlots, i
     if (gp >= 0) full[gp] = gathered[k];
 }
 
-__global__ void k_init_control(Control* ctl, unsigned nextJob) {
-    ctl->nextJob = nextJob;
+__global__ void k_init_control(Control* ctl) {                     // a new frame stream: job ids restart at 0
+    ctl->nextJob = 0; ctl->jobEnd = 0; ctl->needRevive = 1; ctl->oldestBusy = 0;
     for (int k = 0; k < 4; k++) ctl->exhausted[k] = 0;
+    ctl->qCount[0] = 0; ctl->qCount[32] = 0;
+}
+// addJobs more jobs for the running stream.  If the pool already ran dry (a pull came back empty), the ids it overshot by
+// were never started: hand them out again and let dead slots pull (k_revive); the tail queue is dropped, every slot is visited.
+__global__ void k_submit(Control* ctl, unsigned addJobs, int streamStart, unsigned nSlots) {
+    bool dry = false;
+    for (int k = 0; k < 4; k++) { dry = dry || ctl->exhausted[k] != 0; ctl->exhausted[k] = 0; }
+    if (ctl->nextJob > ctl->jobEnd) { ctl->nextJob = ctl->jobEnd; dry = true; }
+    ctl->jobEnd += addJobs;
+    ctl->needRevive = dry ? 1u : 0u;
+    if (streamStart) { ctl->needRevive = 2u; ctl->nextJob = min(nSlots, addJobs); }      // fresh pool: slot i starts job i, no pulling
     ctl->qCount[0] = 0; ctl->qCount[32] = 0;
 }
 
@@ -657,17 +706,22 @@ struct pt_ctx {
     DevScene sc{};
     // shard
     std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; unsigned* dPixXY = nullptr; int* dAllMaps = nullptr;
-    float4* dFrame = nullptr;
+    static constexpr int IMAGES = 4;
+    float4* dImage[IMAGES] = {nullptr, nullptr, nullptr, nullptr}; int curImage = 0;      // FRAME images (more than one only after pt_next_image)
     // path pool
     int poolSlots = 0;              // 0 = automatic: jobs/5 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
     int poolActive = 0; int allocSlots = 0; bool allocTrans = false;
     State st{};
     unsigned* dQueue[2] = {nullptr, nullptr};      // dense slot queues of the batch tail, by iteration parity
-    float4* dColbuf = nullptr; size_t colbufElems = 0;
-    int* dSeeds = nullptr; int seedsCap = 0;
+    float4* dColbuf = nullptr; int* dSeeds = nullptr; int ringFrames = 0;      // per-frame rings of the stream (Batch)
+    // frame-stream scheduler (host view)
+    struct Entry { unsigned jobEnd, f0; int nFrames, firstFrame, image; };      // a submitted, not yet accumulated batch
+    std::deque<Entry> pending;
+    FrameIn streamIn{};             // frame inputs the running stream was started with
+    unsigned streamFrames = 0, streamJobs = 0, lastNextJob = 0, lastDelta = 0, launched = 0; int lastCheck = 24, iter = 0; bool draining = false;
     FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
     Control* hCtl = nullptr;        // pinned copy for the host's polls
-    FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr; int hSeedsCap = 0;   // pinned staging
+    FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr;   // pinned staging (hSeeds: ring like dSeeds)
     // options / stats
     bool countStats = false, timing = false;
     int ldsBudget = 20 * 1024;
@@ -966,77 +1020,79 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
 #undef EP_T
 }
 
-int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
-    if (nFrames < 1) return fail(PT_ERR_ARG, "n_frames must be >= 1");
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    int rc;
-    if (c->sceneDirty && (rc = buildScene(c))) return rc;
-    // parameter checks (scope: SURVEY.md §2)
-    const float* P = c->params.data();
-    const bool direct = P[9] != 1.0f;                            // RAYTRACING == 0: directDiffuse (frag.glsl:655-681, :911-912)
-    if (direct && c->anySubsurface) {
-        if (c->sc.numObj > (int)FL_PROBE_OBJ_MASK) return fail(PT_ERR_UNSUPPORTED, "directDiffuse with subsurface materials supports at most 127 objects (BVHs)");
-        if (c->ambiguousTriObj) return fail(PT_ERR_SCENE, "directDiffuse with subsurface materials needs every triangle to belong to one BVH (hit.parentID, frag.glsl:573)");
-    }
-    if (P[10] != 0.0f) return fail(PT_ERR_UNSUPPORTED, "DEBUG traversal heat-map (frag.glsl:539-547) is out of scope");
-    if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
-    if (!(P[4] >= 1.0f) || P[4] > 255.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,255]");
-    if (!(P[5] > 0.0f) || P[5] > 255.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,255]");
-    size_t nJobs64 = (size_t)c->nLocal * (size_t)nFrames;
-    if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
-    if (c->poolSlots > 0) c->poolActive = c->poolSlots;
-    else {
-        size_t want = std::min<size_t>(std::max<size_t>(nJobs64 / 5, (size_t)1 << 20), (size_t)1 << 22);
-        c->poolActive = (int)((std::min<size_t>(want, std::max<size_t>(nJobs64, BLOCK)) + BLOCK - 1) / BLOCK * BLOCK);
-    }
-    if ((rc = ensurePool(c))) return rc;
-    // per-batch inputs
-    if (c->seedsCap < nFrames) { if (c->dSeeds) HIP_TRY(hipFree(c->dSeeds)); HIP_TRY(hipMalloc((void**)&c->dSeeds, (size_t)nFrames * 4)); c->seedsCap = nFrames; }
-    if (c->hSeedsCap < nFrames) { if (c->hSeeds) HIP_TRY(hipHostFree(c->hSeeds)); HIP_TRY(hipHostMalloc((void**)&c->hSeeds, (size_t)nFrames * 4, hipHostMallocDefault)); c->hSeedsCap = nFrames; }
-    std::memcpy(c->hSeeds, seeds, (size_t)nFrames * 4);
-    HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)nFrames * 4, hipMemcpyHostToDevice, s));
-    size_t needCol = (size_t)nFrames * (size_t)c->nSlotsImg;
-    if (c->colbufElems < needCol) { if (c->dColbuf) { HIP_TRY(hipStreamSynchronize(s)); HIP_TRY(hipFree(c->dColbuf)); } HIP_TRY(hipMalloc((void**)&c->dColbuf, needCol * 16)); c->colbufElems = needCol; }
-    FrameIn& fin = *c->hFrameIn;
-    std::memcpy(fin.params, P, 48); std::memcpy(fin.origin, c->origin.data(), 12); std::memcpy(fin.rotation, c->rotation.data(), 12); std::memcpy(fin.mouse, c->mouse.data(), 12);
-    HIP_TRY(hipMemcpyAsync(c->dFrameIn, c->hFrameIn, sizeof(FrameIn), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, s, c->sc, c->dFrameIn, c->dFc, c->dEllip);
+// ------------------------------------------------------------------------------------------------ frame-stream scheduler
+// A batch is SUBMITTED (its jobs are appended to the running stream, or a new stream starts) and later RETIRED (all its
+// pixel-frame jobs done -> k_accumulate adds its frames to the FRAME image, in u_frameCount order).  Between the two the host
+// only PUMPS: it launches iterations (intersect + shade) in groups and polls the scheduler words after each group.
+//   pt_render_batch        = submit + pump until the batch is retired
+//   pt_render_batch_async  = submit + pump until most of its jobs have been handed out; the rest, and the jobs still in flight,
+//                            are finished underneath the next batch (or by pt_finish_image / any synchronous entry point)
 
+Batch streamBatch(const pt_ctx* c) {
     Batch b;
-    b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount; b.nJobs = (unsigned)nJobs64;
-    b.firstFrame = firstFrame; b.nFrames = nFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
+    b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount;
+    b.ringFrames = (unsigned)c->ringFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
     if (c->nLocal >= 2) {                                     // ceil(2^(31+l)/d), exact for every job < 2^31
         unsigned d = (unsigned)c->nLocal; int l = 0;
         while ((1ull << l) < d) l++;
         unsigned long long m = ((1ull << (31 + l)) + d - 1) / d;
         b.divM = (unsigned)m; b.divS = (unsigned)(l - 1);
     } else { b.divM = 0; b.divS = 0; }
-    int N = c->poolActive;
-    unsigned first = (unsigned)std::min<size_t>((size_t)N, nJobs64);
-    // One pool on one stream.  (Two half-pools on two streams, shading one half underneath the intersection of the other, were
-    // measured on C3 at 812 vs 1210 Msamples/s: the shading kernel's HBM traffic stretches the intersect kernel's memory latency
-    // far more than the overlap gains — DESIGN.md "rejected".)
-    PoolRun pr;
-    pr.stream = s; pr.st = c->st; pr.launched = first; pr.iter = 0;
-    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl, first);
-    int gridN = (N + BLOCK - 1) / BLOCK;
-    if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<true>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
-    else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_generate<false>, dim3(gridN), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+    return b;
+}
 
+int retireFront(pt_ctx* c) {
+    const pt_ctx::Entry e = c->pending.front();
+    c->pending.pop_front();
+    hipStream_t s = c->stream;
+    Batch b = streamBatch(c);
+    int gridA = (c->nSlotsImg + BLOCK - 1) / BLOCK;
+    TIMED_LAUNCH(3, hipLaunchKernelGGL(k_accumulate, dim3(gridA), dim3(BLOCK), 0, s, b, c->dFc, c->dImage[e.image], e.f0, e.nFrames, e.firstFrame));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
+// PUMP_IDLE: every batch retired.  PUMP_ISSUED: the jobs not yet handed out fit into roughly one more group of iterations
+// (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
+// rows are still owned by unretired batches.
+int pump(pt_ctx* c, PumpUntil until, int arg) {
+    if (c->pending.empty()) return 0;
+    hipStream_t s = c->stream;
+    const float* P = c->params.data();
+    const bool direct = P[9] != 1.0f;
+    const Batch b = streamBatch(c);
+    const int N = c->poolActive;
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
+    auto satisfied = [&]() {
+        if (c->pending.empty()) return true;
+        switch (until) {
+            case PUMP_IDLE: return false;
+            case PUMP_ISSUED: return c->draining || (int64_t)c->streamJobs - (int64_t)c->lastNextJob <= (int64_t)c->lastDelta;
+            case PUMP_IMAGE: for (const auto& e : c->pending) if (e.image == arg) return false; return true;
+            case PUMP_RING: return (int)(c->streamFrames - c->pending.front().f0) <= arg;
+        }
+        return true;
+    };
     // every job retires within SAMPLE_RES * ceil(MAX_BOUNCES) iterations of being started, and a slot runs at most
-    // ceil(jobs / slots) jobs back to back: a batch that exceeds this bound (x2) is a scheduler bug, not work
-    const uint64_t maxIters = 2 * ((nJobs64 + first - 1) / first + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
-    // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
-    // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
-    // The host only polls: while jobs remain the end is at least one whole job (>= SAMPLE_RES iterations) away, so it looks
-    // every 24 iterations, in the tail every 8; each look shrinks the launch grids to the live count and ends the batch at 0.
-    bool draining = false, done = false;
-    while (!done) {
-        if ((uint64_t)pr.iter > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        const int CHECK = draining ? 8 : 24;
+    // ceil(jobs / slots) jobs back to back: a pump that exceeds this bound (x2) is a scheduler bug, not work
+    const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + (uint64_t)N;
+    const uint64_t maxIters = 2 * ((outstanding + N - 1) / N + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
+    uint64_t iters = 0;
+    while (!satisfied()) {
+        if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
+        // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
+        // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
+        // The host only polls: while jobs remain the end is at least one whole job (>= SAMPLE_RES iterations) away, so it looks
+        // every 24 iterations, in the tail every 8; each look shrinks the launch grids to the live count.
+        int CHECK = c->draining ? 8 : 24;
+        if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
+            int64_t left = (int64_t)c->streamJobs - (int64_t)c->lastNextJob - (int64_t)c->lastDelta / 2;
+            int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));
+            CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, left / perIter));
+        }
         for (int k = 0; k < CHECK; k++) {
+            PoolRun pr; pr.stream = s; pr.st = c->st; pr.launched = c->launched; pr.iter = c->iter;
             const int grid = std::max(1, (int)((pr.launched + BLOCK - 1) / BLOCK));
             if (c->extendMode == 0) {
                 if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
@@ -1052,25 +1108,119 @@ int renderBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds) {
             if (direct) SHADE_X(false, true);
             else if (c->trans) SHADE_X(true, false);
             else SHADE_X(false, false);
-            pr.iter++;
+            c->iter = (c->iter + 1) & 0x3fffffff;
+            iters++;
+        }
+        // has the oldest batch been handed out completely (as of the previous look)?  then see whether it is still in flight
+        const bool scan = !c->pending.empty() && c->lastNextJob >= c->pending.front().jobEnd;
+        if (scan) {
+            HIP_TRY(hipMemsetAsync(&c->dCtl->oldestBusy, 0, 4, s));
+            hipLaunchKernelGGL(k_scan_inflight, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, c->st, N, c->pending.front().f0 + (unsigned)c->pending.front().nFrames, c->dCtl);
         }
         HIP_TRY(hipMemcpyAsync(c->hCtl, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (c->hCtl->exhausted[(pr.iter + 3) & 3]) {              // iteration pr.iter reads the queue: its count is exact
-            draining = true;
-            pr.launched = c->hCtl->qCount[32 * (pr.iter & 1)];
-            done = pr.launched == 0;
-        } else if (c->hCtl->nextJob >= b.nJobs) {
-            draining = true;                                       // jobs just ran out; the queue starts within two iterations
+        const Control& h = *c->hCtl;
+        c->lastDelta = h.nextJob >= c->lastNextJob ? h.nextJob - c->lastNextJob : 0; c->lastCheck = CHECK;
+        c->lastNextJob = h.nextJob;
+        bool allDead = false;
+        if (h.exhausted[(c->iter + 3) & 3]) {                      // the next iteration reads the queue: its count is exact
+            c->draining = true;
+            c->launched = h.qCount[32 * (c->iter & 1)];
+            allDead = c->launched == 0;
+        } else if (h.nextJob >= c->streamJobs) {
+            c->draining = true;                                    // jobs just ran out; the queue starts within two iterations
         }
+        int rc;
+        if (allDead) { while (!c->pending.empty()) if ((rc = retireFront(c))) return rc; }
+        else if (scan && !h.oldestBusy) { if ((rc = retireFront(c))) return rc; }
     }
-    const uint64_t iters = (uint64_t)pr.iter;
-    int gridA = (c->nSlotsImg + BLOCK - 1) / BLOCK;
-    TIMED_LAUNCH(3, hipLaunchKernelGGL(k_accumulate, dim3(gridA), dim3(BLOCK), 0, s, b, c->dFc, c->dFrame));
-    HIP_TRY(hipGetLastError());
     c->hostCnt[PT_CNT_ITERATIONS] += iters;
     c->hostCnt[PT_CNT_EXTEND_LAUNCHES] += iters;
     return 0;
+}
+
+int flushStream(pt_ctx* c) {
+    if (c->pending.empty()) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    return pump(c, PUMP_IDLE, 0);
+}
+
+int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bool async) {
+    if (nFrames < 1) return fail(PT_ERR_ARG, "n_frames must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc;
+    // parameter checks (scope: SURVEY.md §2)
+    if (c->params.size() < 12) return fail(PT_ERR_ARG, "Parameters (binding 4) not set");
+    const float* P = c->params.data();
+    const bool direct = P[9] != 1.0f;                            // RAYTRACING == 0: directDiffuse (frag.glsl:655-681, :911-912)
+    if (P[10] != 0.0f) return fail(PT_ERR_UNSUPPORTED, "DEBUG traversal heat-map (frag.glsl:539-547) is out of scope");
+    if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
+    if (!(P[4] >= 1.0f) || P[4] > 255.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,255]");
+    if (!(P[5] > 0.0f) || P[5] > 255.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,255]");
+    size_t nJobs64 = (size_t)c->nLocal * (size_t)nFrames;
+    if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
+    FrameIn fin;
+    std::memcpy(fin.params, P, 48); std::memcpy(fin.origin, c->origin.data(), 12); std::memcpy(fin.rotation, c->rotation.data(), 12); std::memcpy(fin.mouse, c->mouse.data(), 12);
+    // the running stream can take this batch if nothing the kernels were launched with changes
+    const int wantRing = (async ? pt_ctx::IMAGES : 1) * nFrames;      // overlapped: room for the batches of as many images as can be pending
+    bool join = !c->pending.empty() && !c->sceneDirty && std::memcmp(&fin, &c->streamIn, sizeof(FrameIn)) == 0 && c->ringFrames >= wantRing &&
+                (uint64_t)c->streamJobs + nJobs64 < (1ull << 31);
+    if (!join && (rc = flushStream(c))) return rc;
+    if (!join) {                                                  // ---- a new stream
+        if (c->sceneDirty && (rc = buildScene(c))) return rc;
+        if (direct && c->anySubsurface) {
+            if (c->sc.numObj > (int)FL_PROBE_OBJ_MASK) return fail(PT_ERR_UNSUPPORTED, "directDiffuse with subsurface materials supports at most 127 objects (BVHs)");
+            if (c->ambiguousTriObj) return fail(PT_ERR_SCENE, "directDiffuse with subsurface materials needs every triangle to belong to one BVH (hit.parentID, frag.glsl:573)");
+        }
+        if (c->poolSlots > 0) c->poolActive = c->poolSlots;
+        else {                                                    // automatic pool (measured on C3, profiles/): a fifth of the batch when it has to drain at the end
+                                                                  // (short tail), 3/8 of it up to 2^23 when batches overlap (no tail: fewer, fatter launches win)
+            size_t want = std::min<size_t>(std::max<size_t>(async ? nJobs64 * 3 / 8 : nJobs64 / 5, (size_t)1 << 20), (size_t)1 << (async ? 23 : 22));
+            c->poolActive = (int)((std::min<size_t>(want, std::max<size_t>(nJobs64, BLOCK)) + BLOCK - 1) / BLOCK * BLOCK);
+        }
+        if ((rc = ensurePool(c))) return rc;
+        if (c->ringFrames < wantRing) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (c->dColbuf) HIP_TRY(hipFree(c->dColbuf));
+            if (c->dSeeds) HIP_TRY(hipFree(c->dSeeds));
+            if (c->hSeeds) HIP_TRY(hipHostFree(c->hSeeds));
+            c->dColbuf = nullptr; c->dSeeds = nullptr; c->hSeeds = nullptr; c->ringFrames = 0;
+            HIP_TRY(hipMalloc((void**)&c->dColbuf, (size_t)wantRing * (size_t)c->nSlotsImg * 16));
+            HIP_TRY(hipMalloc((void**)&c->dSeeds, (size_t)wantRing * 4));
+            HIP_TRY(hipHostMalloc((void**)&c->hSeeds, (size_t)wantRing * 4, hipHostMallocDefault));
+            c->ringFrames = wantRing;
+        }
+        c->streamIn = fin; *c->hFrameIn = fin;
+        HIP_TRY(hipMemcpyAsync(c->dFrameIn, c->hFrameIn, sizeof(FrameIn), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, s, c->sc, c->dFrameIn, c->dFc, c->dEllip);
+        hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl);
+        HIP_TRY(hipMemsetAsync(c->st.G1, 0, (size_t)c->poolActive * 16, s));       // every slot dead
+        c->streamFrames = 0; c->streamJobs = 0; c->lastNextJob = 0; c->lastDelta = 0; c->lastCheck = 24; c->iter = 0;
+    } else if ((int)(c->streamFrames - c->pending.front().f0) + nFrames > c->ringFrames) {
+        if ((rc = pump(c, PUMP_RING, c->ringFrames - nFrames))) return rc;        // wait for ring rows
+        if (c->pending.empty()) return submitBatch(c, firstFrame, nFrames, seeds, async);   // the stream ended meanwhile: start over
+    }
+    // ---- append
+    const unsigned f0 = c->streamFrames;
+    for (int f = 0; f < nFrames; f++) c->hSeeds[(f0 + (unsigned)f) % (unsigned)c->ringFrames] = seeds[f];
+    {
+        unsigned r0 = f0 % (unsigned)c->ringFrames, n0 = std::min<unsigned>((unsigned)nFrames, (unsigned)c->ringFrames - r0);
+        HIP_TRY(hipMemcpyAsync(c->dSeeds + r0, c->hSeeds + r0, (size_t)n0 * 4, hipMemcpyHostToDevice, s));
+        if (n0 < (unsigned)nFrames) HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)(nFrames - n0) * 4, hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(k_submit, dim3(1), dim3(1), 0, s, c->dCtl, (unsigned)nJobs64, join ? 0 : 1, (unsigned)c->poolActive);
+    const Batch b = streamBatch(c);
+    const int N = c->poolActive;
+    if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<true>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+    else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<false>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+    c->streamFrames += (unsigned)nFrames; c->streamJobs += (unsigned)nJobs64;
+    pt_ctx::Entry e; e.jobEnd = c->streamJobs; e.f0 = f0; e.nFrames = nFrames; e.firstFrame = firstFrame; e.image = c->curImage;
+    c->pending.push_back(e);
+    c->draining = false; c->launched = (unsigned)N;              // (if the pool had run dry, k_submit dropped the tail queue)
+    HIP_TRY(hipGetLastError());
+    if (async) return pump(c, PUMP_ISSUED, 0);
+    return pump(c, PUMP_IDLE, 0);
 }
 
 int resolveTimes(pt_ctx* c) {
@@ -1119,8 +1269,8 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
         HIP_TRY(hipMalloc((void**)&c->dPixXY, xy.size() * 4));
         HIP_TRY(hipMemcpy(c->dPixXY, xy.data(), xy.size() * 4, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc((void**)&c->dFrame, (size_t)c->nSlotsImg * 16));
-    HIP_TRY(hipMemset(c->dFrame, 0, (size_t)c->nSlotsImg * 16));
+    HIP_TRY(hipMalloc((void**)&c->dImage[0], (size_t)c->nSlotsImg * 16));
+    HIP_TRY(hipMemset(c->dImage[0], 0, (size_t)c->nSlotsImg * 16));
     HIP_TRY(hipMalloc((void**)&c->dFrameIn, sizeof(FrameIn)));
     HIP_TRY(hipMalloc((void**)&c->dFc, sizeof(FrameConst)));
     HIP_TRY(hipMalloc((void**)&c->dCtl, sizeof(Control)));
@@ -1136,9 +1286,10 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
 int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
     hipSetDevice(c->device);
+    flushStream(c);
     hipStreamSynchronize(c->stream);
     for (float4* p : c->dTexData) if (p) hipFree(p);
-    void* ptrs[] = {c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dFrame, c->st.G0, c->st.G1, c->st.G2,
+    void* ptrs[] = {c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hCtl) hipHostFree(c->hCtl);
@@ -1186,28 +1337,69 @@ int pt_set_texture(pt_ctx* c, int index, int w, int h, const uint8_t* rgba8) {
 int pt_reset_frame(pt_ctx* c) {
     if (!c) return fail(PT_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->dFrame, 0, (size_t)c->nSlotsImg * 16, c->stream));
+    int rc;
+    if ((rc = flushStream(c))) return rc;
+    HIP_TRY(hipMemsetAsync(c->dImage[c->curImage], 0, (size_t)c->nSlotsImg * 16, c->stream));
     return PT_OK;
 }
 
-int pt_render(pt_ctx* c, int frame_count, int seed) { if (!c) return fail(PT_ERR_ARG, "null context"); int32_t s = seed; return renderBatch(c, frame_count, 1, &s); }
+int pt_render(pt_ctx* c, int frame_count, int seed) { if (!c) return fail(PT_ERR_ARG, "null context"); int32_t s = seed; return submitBatch(c, frame_count, 1, &s, false); }
 int pt_render_batch(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
     if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch: null argument");
-    return renderBatch(c, first_frame, n_frames, seeds);
+    return submitBatch(c, first_frame, n_frames, seeds, false);
+}
+int pt_render_batch_async(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
+    if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch_async: null argument");
+    return submitBatch(c, first_frame, n_frames, seeds, true);
 }
 
-int pt_synchronize(pt_ctx* c) { if (!c) return fail(PT_ERR_ARG, "null context"); HIP_TRY(hipSetDevice(c->device)); HIP_TRY(hipStreamSynchronize(c->stream)); return PT_OK; }
+int pt_next_image(pt_ctx* c) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    const int next = (c->curImage + 1) % pt_ctx::IMAGES;
+    if (!c->dImage[next]) HIP_TRY(hipMalloc((void**)&c->dImage[next], (size_t)c->nSlotsImg * 16));
+    int rc;
+    if ((rc = pump(c, PUMP_IMAGE, next))) return rc;              // nothing may still be on its way into the image taken over
+    c->curImage = next;
+    HIP_TRY(hipMemsetAsync(c->dImage[next], 0, (size_t)c->nSlotsImg * 16, c->stream));
+    return PT_OK;
+}
+
+int pt_finish_image(pt_ctx* c, int age) {
+    if (!c || age < 0 || age >= pt_ctx::IMAGES) return fail(PT_ERR_ARG, "pt_finish_image: age must be in [0,3] (0 = current image)");
+    HIP_TRY(hipSetDevice(c->device));
+    return pump(c, PUMP_IMAGE, (c->curImage + pt_ctx::IMAGES - age) % pt_ctx::IMAGES);
+}
+
+int pt_image_device(pt_ctx* c, int age, void** dev_ptr, size_t* n_pixels) {
+    if (!c || !dev_ptr || !n_pixels || age < 0 || age >= pt_ctx::IMAGES) return fail(PT_ERR_ARG, "pt_image_device: bad argument");
+    float4* img = c->dImage[(c->curImage + pt_ctx::IMAGES - age) % pt_ctx::IMAGES];
+    if (!img) return fail(PT_ERR_ARG, "pt_image_device: no image of that age yet (too few pt_next_image calls)");
+    *dev_ptr = img; *n_pixels = (size_t)c->nSlotsImg;
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx* c) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = flushStream(c))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
 
 int pt_read_frame(pt_ctx* c, float* out) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_read_frame: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
+    float4* const dFrame = c->dImage[c->curImage];
     if (c->shardCount == 1) {
-        HIP_TRY(hipMemcpyAsync(out, c->dFrame, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out, dFrame, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         return PT_OK;
     }
     std::vector<float> tmp((size_t)c->nLocal * 4);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), c->dFrame, tmp.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), dFrame, tmp.size() * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int k = 0; k < c->nLocal; k++) std::memcpy(out + 4 * (size_t)c->pixList[k], tmp.data() + 4 * (size_t)k, 16);
     return PT_OK;
@@ -1217,10 +1409,11 @@ int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out
     if (!c || !rgb_out) return fail(PT_ERR_ARG, "pt_read_display: null argument");
     if (c->shardCount != 1) return fail(PT_ERR_ARG, "pt_read_display needs the whole image: gather the shards first (shard_count must be 1)");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
     size_t bytes = (size_t)c->W * c->H * 3;
     unsigned char* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, bytes));
-    hipLaunchKernelGGL(k_display, dim3((unsigned)(((size_t)c->W * c->H + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->dFrame, c->W, c->H, (float)frame_count, java_bytes, d);
+    hipLaunchKernelGGL(k_display, dim3((unsigned)(((size_t)c->W * c->H + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->dImage[c->curImage], c->W, c->H, (float)frame_count, java_bytes, d);
     hipError_t e = hipMemcpyAsync(rgb_out, d, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d);
@@ -1230,7 +1423,7 @@ int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out
 
 int pt_frame_device(pt_ctx* c, void** dev_ptr, size_t* n_pixels) {
     if (!c || !dev_ptr || !n_pixels) return fail(PT_ERR_ARG, "pt_frame_device: null argument");
-    *dev_ptr = c->dFrame; *n_pixels = (size_t)c->nSlotsImg;
+    *dev_ptr = c->dImage[c->curImage]; *n_pixels = (size_t)c->nSlotsImg;
     return PT_OK;
 }
 
@@ -1268,6 +1461,7 @@ int pt_unshard(pt_ctx* c, const void* gathered_dev, void* full_dev) {
 int pt_set_stream(pt_ctx* c, void* hip_stream) {
     if (!c) return fail(PT_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     return PT_OK;
@@ -1275,6 +1469,7 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
 
 int pt_set_option(pt_ctx* c, int option, int64_t value) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    { int rc; if ((rc = flushStream(c))) return rc; }
     switch (option) {
         case 0: if (value != 0 && (value < BLOCK || value > (1 << 26))) return fail(PT_ERR_ARG, "path slots must be 0 (automatic) or in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
         case 1: c->countStats = value != 0; return PT_OK;
@@ -1293,6 +1488,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
 int pt_get_counters(pt_ctx* c, uint64_t* out, int n) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_get_counters: null argument");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     Control h;
     HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
@@ -1306,8 +1502,9 @@ int pt_get_counters(pt_ctx* c, uint64_t* out, int n) {
 int pt_reset_counters(pt_ctx* c) {
     if (!c) return fail(PT_ERR_ARG, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
+    HIP_TRY(hipMemset(c->dCtl->cnt, 0, sizeof(Control::cnt)));
     std::memset(c->hostCnt, 0, sizeof(c->hostCnt));
     for (auto& k : c->kt) { k.used = 0; k.ms = 0; k.launches = 0; k.each.clear(); }
     return PT_OK;
@@ -1374,7 +1571,8 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     HIP_TRY(hipMemcpy(c->dFrameIn, &fin, sizeof(fin), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, c->stream, c->sc, c->dFrameIn, c->dFc, c->dEllip);
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
-    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, c->stream, c->dCtl, 0u);
+    { int rc2; if ((rc2 = flushStream(c))) return rc2; }
+    hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, c->stream, c->dCtl);
     hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, 0, (int)np, c->dCtl);
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> h(np * 4);

@@ -37,6 +37,10 @@ def lib():
         L.pt_reset_frame.argtypes = [vp]
         L.pt_render.argtypes = [vp, ci, ci]
         L.pt_render_batch.argtypes = [vp, ci, ci, vp]
+        L.pt_render_batch_async.argtypes = [vp, ci, ci, vp]
+        L.pt_next_image.argtypes = [vp]
+        L.pt_finish_image.argtypes = [vp, ci]
+        L.pt_image_device.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz)]
         L.pt_synchronize.argtypes = [vp]
         L.pt_read_frame.argtypes = [vp, vp]
         L.pt_read_display.argtypes = [vp, ci, ci, vp]
@@ -129,6 +133,22 @@ class Renderer:
     def render_batch(self, first_frame, seeds):
         s = np.ascontiguousarray(seeds, dtype=np.int32)
         _check(self._L.pt_render_batch(self._h, int(first_frame), int(s.size), s.ctypes.data))
+
+    # overlapped batches: the path pool keeps running from one batch into the next (include/pt_api.h)
+    def render_batch_async(self, first_frame, seeds):
+        s = np.ascontiguousarray(seeds, dtype=np.int32)
+        _check(self._L.pt_render_batch_async(self._h, int(first_frame), int(s.size), s.ctypes.data))
+
+    def next_image(self):
+        _check(self._L.pt_next_image(self._h))
+
+    def finish_image(self, age=0):
+        _check(self._L.pt_finish_image(self._h, int(age)))
+
+    def image_device(self, age=0):
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self._L.pt_image_device(self._h, int(age), C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def synchronize(self):
         _check(self._L.pt_synchronize(self._h))

@@ -18,9 +18,10 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
 
-def frame_tensor(renderer, device):
-    """The shard's packed accumulator (n_slots, 4) as a torch tensor aliasing the library's device memory."""
-    ptr, n = renderer.frame_device()
+def frame_tensor(renderer, device, age=0):
+    """The shard's packed accumulator (n_slots, 4) as a torch tensor aliasing the library's device memory
+    (age 1: the previous image of the two that alternate under pt_next_image)."""
+    ptr, n = renderer.image_device(age)
     return torch.as_tensor(_DevArray(ptr, (n, 4)), device=device)
 
 

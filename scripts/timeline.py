@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Per-iteration timeline of one wavefront batch from a rocprofv3 --kernel-trace CSV.
 
-usage: timeline.py <dir with *_kernel_trace.csv> [batch_index]
-Prints, for the chosen batch (delimited by k_frame_setup launches), one line per group of 8 iterations: the extend and shade
+usage: timeline.py <dir with *_kernel_trace.csv> [window]      window 0: whole trace; k > 0: after the k-th k_accumulate;
+                                                               k < 0: from the k_accumulate before the k-th last one
+Prints, for the chosen window, one line per group of 8 iterations: the extend and shade
 durations, the idle gap between kernels, and the running clock - shows where a batch spends its time (ramp, steady state, drain).
 """
 import csv
@@ -11,7 +12,7 @@ import re
 import sys
 
 
-def main(d, which=-1, group=8):
+def main(d, which=0, group=8):
     f = glob.glob(f"{d}/**/*_kernel_trace.csv", recursive=True)[0]
     rows = []
     for r in csv.DictReader(open(f)):
@@ -21,11 +22,9 @@ def main(d, which=-1, group=8):
     rows.sort()
     starts = [i for i, r in enumerate(rows) if r[2] == "k_frame_setup"]
     # a batch = from a k_generate launch to the k_accumulate that follows
-    gens = [i for i, r in enumerate(rows) if r[2] == "k_generate"]
     accs = [i for i, r in enumerate(rows) if r[2] == "k_accumulate"]
-    g = gens[which]
-    a = min(i for i in accs if i > g)
-    batch = rows[g:a + 1]
+    # window: from the accumulate launch number `which` (negative: from the end) to the last launch of the trace
+    batch = rows if which == 0 else (rows[accs[which] + 1:] if which > 0 else rows[(accs[which - 1] + 1 if len(accs) >= -which + 1 else 0):])
     t0 = batch[0][0]
     print(f"batch: {len(batch)} launches, span {(batch[-1][1] - t0) / 1e6:.3f} ms, busy {sum(e - s for s, e, _ in batch) / 1e6:.3f} ms")
     by = {}
@@ -48,9 +47,11 @@ def main(d, which=-1, group=8):
                 ext = sh = oth = gap = 0.0; n_in = 0
         else:
             oth += e - s
+            if n in ("k_accumulate", "k_revive", "k_submit"):
+                print(f"      {(s - t0) / 1e6:9.3f} ms  {n}  ({(e - s) / 1e3:.1f} us)")
     if n_in:
         print(f"{it:5d} {(prev_end - t0) / 1e6:9.3f} {ext / n_in / 1e3:9.1f} {sh / n_in / 1e3:9.1f} {oth / n_in / 1e3:9.1f} {gap / n_in / 1e3:7.1f}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else -1)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 0)

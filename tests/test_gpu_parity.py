@@ -236,6 +236,65 @@ def test_full_size_properties_c3(pt, oracle, renderer_mod):
     assert np.array_equal(a[::27, ::24], ref[::27, ::24])
 
 
+@pytest.mark.parametrize("slots,batch", [(2048, 3), (1 << 16, 1), (4096, 6)])
+def test_overlapped_batches_equal_synchronous(pt, oracle, renderer_mod, slots, batch):
+    """pt_render_batch_async / pt_next_image / pt_finish_image: consecutive batches share one running path pool (no drain between
+    them; with (65536, 1) the pool is larger than a batch and runs dry in between, so dead slots are revived) - same bits as the
+    synchronous calls, image after image"""
+    import torch
+    from pathtracer_0_amd import shard
+    W, H = 128, 72
+    wl = pt.scenes.build("C3", W, H)
+    sc = oracle.Scene.from_workload(wl)
+    dev = torch.device("cuda", 0)
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("path_slots", slots)
+    r.set_option("count_stats", 1)
+    r.load_workload(wl)
+    images = []
+    n_img, n_frames = 3, 6
+    seeds = {k: [(977 * k + 31 * f) % 10000 for f in range(1, n_frames + 1)] for k in range(n_img)}
+    for k in range(n_img):
+        r.next_image()
+        for first in range(1, n_frames + 1, batch):
+            r.render_batch_async(first, seeds[k][first - 1:first - 1 + batch])
+        if k > 0:
+            r.finish_image(1)
+            images.append(shard.frame_tensor(r, dev, age=1).cpu().numpy().reshape(H, W, 4).copy())
+    images.append(r.read_frame().copy())          # completes the last image
+    cnt = r.counters()
+    r.close()
+    total = 0
+    for k in range(n_img):
+        ref, ocnt = oracle.render_frames(sc, W, H, 1, n_frames, seeds[k], nthreads=8)
+        assert np.array_equal(images[k], ref), k
+        total += int(ocnt[4])
+    assert cnt["samples"] == total
+
+
+def test_overlapped_batches_with_a_camera_move(pt, oracle, renderer_mod):
+    """a change of the frame inputs between two asynchronous batches ends the running stream first (include/pt_api.h)"""
+    W, H = 96, 54
+    wl = pt.scenes.build("C2", W, H)
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("path_slots", 1024)
+    r.load_workload(wl)
+    r.reset_frame()
+    r.render_batch_async(1, [11, 22])
+    moved = wl.buffers[0].copy(); moved[0] += 0.25
+    r.set_buffer(0, moved)
+    r.render_batch_async(3, [33, 44])
+    got = r.read_frame().copy()
+    r.close()
+    sc = oracle.Scene.from_workload(wl)
+    ref = np.zeros((H, W, 4), np.float32)
+    oracle.render_frames(sc, W, H, 1, 2, [11, 22], frame=ref, nthreads=8)
+    b = dict(wl.buffers); b[0] = moved
+    sc2 = oracle.Scene.from_workload(pt.scenes.Workload(wl.name, W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info))
+    oracle.render_frames(sc2, W, H, 3, 2, [33, 44], frame=ref, nthreads=8)
+    assert np.array_equal(got, ref)
+
+
 def test_two_process_shards_on_one_gpu(pt):
     """one process per shard (as on the 8-GPU node), here 2 ranks sharing cuda:0, gloo collective"""
     import os, subprocess, sys
