@@ -26,8 +26,12 @@ public final class PtNative {
     /** glUniform1i(u_frameCount), glUniform1i(u_seed), glDrawArrays(GL_TRIANGLES,0,6) (dispatch.java:697-705) */
     public static native void render(long ctx, int frameCount, int seed);
     public static native void renderBatch(long ctx, int firstFrame, int[] seeds);
+    /** the same draw call left in flight, as the GL driver leaves it until glFinish (pt_render_batch_async, one frame) */
+    public static native void renderAsync(long ctx, int frameCount, int seed);
     /** glFinish() */
     public static native void synchronize(long ctx);
     /** glReadPixels of the RGBA32F FRAME image into a direct FloatBuffer of width*height*4 floats */
     public static native void readFrame(long ctx, Buffer rgbaOut);
+    /** functions.screenshot's pixels (dispatch.java:804-833): width*height*3 bytes, top row first; javaBytes = keep its signed-byte packing */
+    public static native void readDisplay(long ctx, int frameCount, boolean javaBytes, Buffer rgbOut);
 }

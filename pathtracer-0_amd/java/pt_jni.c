@@ -43,6 +43,13 @@ JNIEXPORT void JNICALL Java_Main_PtNative_renderBatch(JNIEnv* env, jclass c, jlo
     (*env)->ReleaseIntArrayElements(env, seeds, s, JNI_ABORT);
     if (rc != PT_OK) throw_rt(env, "pt_render_batch");
 }
+JNIEXPORT void JNICALL Java_Main_PtNative_renderAsync(JNIEnv* env, jclass c, jlong h, jint frameCount, jint seed) {
+    int32_t s = (int32_t)seed;
+    CHECK(pt_render_batch_async(CTX(h), frameCount, 1, &s), "pt_render_batch_async");
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_readDisplay(JNIEnv* env, jclass c, jlong h, jint frameCount, jboolean javaBytes, jobject out) {
+    CHECK(pt_read_display(CTX(h), frameCount, javaBytes ? 1 : 0, (uint8_t*)(*env)->GetDirectBufferAddress(env, out)), "pt_read_display");
+}
 JNIEXPORT void JNICALL Java_Main_PtNative_synchronize(JNIEnv* env, jclass c, jlong h) { CHECK(pt_synchronize(CTX(h)), "pt_synchronize"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_readFrame(JNIEnv* env, jclass c, jlong h, jobject out) {
     CHECK(pt_read_frame(CTX(h), (float*)(*env)->GetDirectBufferAddress(env, out)), "pt_read_frame");

@@ -43,7 +43,7 @@ def main(d):
                 a[0] += 1
                 a[1] += float(row["Counter_Value"])
     if agg:
-        print("\n## HBM traffic counters (separate --pmc passes: bench.py --steps 1 --warmup 0 --frames-per-step 4 --no-roofline)")
+        print("\n## HBM traffic counters (separate --pmc passes: bench.py --steps 1 --warmup 0 --frames-per-step 16 --no-roofline)")
         print("kernel,launches,FETCH_SIZE_KiB_per_launch(raw),WRITE_SIZE_KiB_per_launch,HBM_MB_per_launch(fetch x2 + write)")
         for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"][1] + kv[1]["WRITE_SIZE"][1])):
             if not k.startswith("k_"):
@@ -52,8 +52,8 @@ def main(d):
             wl, ws = v["WRITE_SIZE"]
             n = max(fl, wl, 1)
             print(f"{k},{n},{fs/max(fl,1):.1f},{ws/max(wl,1):.1f},{(2*fs/max(fl,1)+ws/max(wl,1))*1024/1e6:.2f}")
-        # per-segment HBM traffic of the wavefront kernels (PMC runs: C3, 4 frames x 8 spp, S = 3.925 segments/sample)
-        seg = 1920 * 1080 * 32 * 3.925
+        # per-segment HBM traffic of the wavefront kernels (PMC runs: C3, 16 frames x 8 spp, S = 3.925 segments/sample)
+        seg = 1920 * 1080 * 128 * 3.925
         out = {}
         for k, v in agg.items():
             base = k.split("<")[0]
@@ -65,7 +65,7 @@ def main(d):
             o["hbm_bytes_per_segment"] = round((2 * o["fetch_kib_raw"] + o["write_kib"]) * 1024 / seg, 2)
             print(f"per segment: {base} HBM bytes (FETCH x2 + WRITE) = {o['hbm_bytes_per_segment']}")
         if len(sys.argv) > 2:
-            json.dump({"source": d, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); C3, 4 frames x 8 spp",
+            json.dump({"source": d, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); C3, 16 frames x 8 spp",
                        "kernels": out}, open(sys.argv[2], "w"), indent=1)
 
 
