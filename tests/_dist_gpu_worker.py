@@ -32,12 +32,30 @@ r.synchronize()
 packed = shard.frame_tensor(r, dev).cpu()
 un = shard.Unsharder(W, H, world, renderer.shard_map, torch.device("cpu"))
 full = shard.gather_frame(packed, un, dst=0)
+# the overlapped schedule bench.py runs: a new image per step, each gathered LAG steps after its submission
+LAG, STEPS = 2, 4
+step_seeds = [[(101 * k + 7 * f) % 10000 for f in (1, 2, 3)] for k in range(STEPS)]
+fulls = []
+for k in range(STEPS):
+    r.next_image()
+    r.render_batch_async(1, step_seeds[k])
+    if k >= LAG:
+        r.finish_image(LAG)
+        torch.cuda.synchronize(dev)
+        fulls.append(shard.gather_frame(shard.frame_tensor(r, dev, age=LAG).cpu(), un, dst=0))
+for age in range(min(LAG, STEPS) - 1, -1, -1):
+    r.finish_image(age)
+    torch.cuda.synchronize(dev)
+    fulls.append(shard.gather_frame(shard.frame_tensor(r, dev, age=age).cpu(), un, dst=0))
 if rank == 0:
     r1 = renderer.Renderer(W, H, device=0)
     r1.load_workload(wl); r1.reset_frame(); r1.render_batch(1, seeds)
-    ref = r1.read_frame()
-    r1.close()
+    ref = r1.read_frame().copy()
     assert np.array_equal(full.numpy(), ref), "sharded render differs from the unsharded one"
+    for k in range(STEPS):
+        r1.reset_frame(); r1.render_batch(1, step_seeds[k])
+        assert np.array_equal(fulls[k].numpy(), r1.read_frame()), f"overlapped sharded step {k} differs from the unsharded synchronous one"
+    r1.close()
     print("DIST_GPU_OK")
 r.close()
 dist.barrier()
