@@ -236,6 +236,39 @@ def test_full_size_properties_c3(pt, oracle, renderer_mod):
     assert np.array_equal(a[::27, ::24], ref[::27, ::24])
 
 
+@pytest.mark.parametrize("name,xs,ys", [("C4", 24, 27), ("C5", 48, 54)])
+def test_full_size_properties_c4_c5(pt, oracle, renderer_mod, name, xs, ys):
+    """BASELINE.json's full C4 (1920x1080, one 100k-triangle BVH) and C5 (3840x2160, 16 bounces) sizes: the overlapped schedule and a
+    3-way tile split reproduce the synchronous image bit for bit; oracle parity on a pixel lattice"""
+    cfg = pt.scenes.CONFIGS[name]
+    W, H = cfg["W"], cfg["H"]
+    wl = pt.scenes.build(name, W, H)
+    seeds = seeds_for(pt, 1, 2)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch(1, seeds)
+    a = r.read_frame().copy()
+    r.next_image()
+    r.render_batch_async(1, seeds[:1]); r.render_batch_async(2, seeds[1:])
+    b = r.read_frame().copy()
+    r.close()
+    assert np.array_equal(a, b)
+    assert np.all(a[..., 3] == 2.0)
+    acc = np.zeros_like(a)
+    for rank in range(3):
+        rr = renderer_mod.Renderer(W, H, shard_rank=rank, shard_count=3)
+        rr.load_workload(wl); rr.reset_frame(); rr.render_batch(1, seeds)
+        part = rr.read_frame(); rr.close()
+        assert np.all(acc[part[..., 3] > 0] == 0)           # shards are disjoint
+        acc += part
+    assert np.array_equal(acc, a)
+    sc = oracle.Scene.from_workload(wl)
+    ref = np.zeros((H, W, 4), np.float32)
+    for i, sd in enumerate(seeds):
+        oracle.render(sc, W, H, 1 + i, sd, ref, nthreads=8, xs=xs, ys=ys)
+    assert np.array_equal(a[::ys, ::xs], ref[::ys, ::xs])
+
+
 @pytest.mark.parametrize("slots,batch", [(2048, 3), (1 << 16, 1), (4096, 6)])
 def test_overlapped_batches_equal_synchronous(pt, oracle, renderer_mod, slots, batch):
     """pt_render_batch_async / pt_next_image / pt_finish_image: consecutive batches share one running path pool (no drain between
