@@ -124,6 +124,18 @@ int pt_unshard(pt_ctx* ctx, const void* gathered_dev, void* full_dev);
 /* Launch everything on this HIP stream (e.g. torch's current stream) instead of the context's own. */
 int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 
+/* ---- the reference's BVH builder on the GPU: BVH(int triIndicesStart, int triIndicesEnd) dispatch.java:1630-1646,
+ * splitTEST :1647-1721, testSplitOnTEST / cost :1722-1752, in double precision, same tree as the Java recursion (and as libpt_host.so).
+ * tri9: per triangle of ONE object 9 doubles = triangle.min, triangle.max, triangle.centroid as the triangle constructor computes them
+ * (:1237-1255).  Outputs are caller-allocated for the worst case of 2*n_tris nodes; node k is the node with the k-th id in creation
+ * (DFS pre-order) order, ids local to the object:
+ *   node_bounds 6 doubles (min, max) | node_links 2 ints (left, right; -1,-1 for a leaf) | node_leaf 2 ints ([start,end) into leaf_tris;
+ *   0,0 for an inner node) | leaf_tris n_tris ints: triangle indices (0-based within the object) in leaf order (= flattenBVH's order)
+ * PT_ERR_SCENE when the root cannot be split (the reference throws at :1644) or a coordinate is NaN.
+ * Needs no context: plug it into the scene producer with pts_set_bvh_builder (include/pt_scene.h). */
+int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_nodes, double* node_bounds, int32_t* node_links,
+                 int32_t* node_leaf, int32_t* leaf_tris, int32_t* max_depth);
+
 /* Tuning knobs: 0 = path slots in flight (default 0 = automatic: jobs/5 clamped to [2^20, 2^22]), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the
  * simple intersect kernel, 3 = retired (accepted, ignored: the batch tail is packed on the device), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,

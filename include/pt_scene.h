@@ -47,6 +47,13 @@ const char* pts_texture_name(pts_scene* s, int index);
  * a texture of that name is already there.  Lines are split on single spaces, as the Java does. */
 int pts_parse_mtls(pts_scene* s, const char* mtl_path, const char* parent_directory);
 
+/* Replace the recursive CPU builder (BVH(int,int), dispatch.java:1630-1752) by an external one with the signature of
+ * pt_build_bvh (include/pt_api.h) for the objects added from now on; fn == NULL restores the built-in builder.  The library
+ * itself stays free of any GPU dependency: the caller passes the function pointer. */
+typedef int (*pts_bvh_builder)(int device, const double* tri9, int64_t n_tris, int32_t* n_nodes, double* node_bounds, int32_t* node_links,
+                               int32_t* node_leaf, int32_t* leaf_tris, int32_t* max_depth);
+int pts_set_bvh_builder(pts_scene* s, pts_bvh_builder fn, int device, const char* (*last_error)(void));
+
 /* scene.addObject(filepath, material, scale, shift, rot) for a regular .obj file
  *                                                                  dispatch.java:867-886, 888-1003
  * parent_directory may be NULL (then "usemtl X" looks for a material named "Xnull", exactly

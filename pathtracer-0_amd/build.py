@@ -1,7 +1,7 @@
 """Build recipes for the native libraries (in-tree, so the .so files travel with the snapshot).
 
   libpt_host.so  g++    host-side scene producers (csrc/host/scene_host.cpp)
-  libpt_hip.so   hipcc  gfx950 render path + C ABI (csrc/hip/pt_hip.hip)
+  libpt_hip.so   hipcc  gfx950 render path + C ABI (csrc/hip/pt_hip.hip), GPU BVH builder (csrc/hip/pt_bvh.hip)
 """
 import os
 import subprocess
@@ -31,11 +31,11 @@ def build_host(force=False):
 
 def build_hip(force=False, extra=()):
     d = os.path.join(HERE, "csrc", "hip")
-    srcs = [os.path.join(d, f) for f in ("pt_hip.hip", "pt_device.hpp", "pt_math.hpp")] + [os.path.join(HERE, "..", "include", "pt_api.h")]
+    srcs = [os.path.join(d, f) for f in ("pt_hip.hip", "pt_bvh.hip", "pt_device.hpp", "pt_math.hpp")] + [os.path.join(HERE, "..", "include", "pt_api.h")]
     out = os.path.join(HERE, "libpt_hip.so")
     if force or _stale(out, srcs):
         hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
-        subprocess.check_call([hipcc] + HIP_FLAGS + list(extra) + ["-o", out, srcs[0]])
+        subprocess.check_call([hipcc] + HIP_FLAGS + list(extra) + ["-o", out, srcs[0], srcs[1]])
     return out
 
 

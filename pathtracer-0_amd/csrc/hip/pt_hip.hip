@@ -1239,6 +1239,8 @@ int resolveTimes(pt_ctx* c) {
 
 // ------------------------------------------------------------------------------------------------ C ABI
 
+int pt_set_error_(int code, const std::string& msg) { return fail(code, msg); }      // for pt_bvh.hip
+
 extern "C" {
 
 const char* pt_last_error(void) { return g_err.c_str(); }

@@ -93,13 +93,16 @@ struct material {
 };
 
 // ---- BVH (dispatch.java:1579-1842) ----
+// java.lang.Math.min/max on doubles: NaN wins, -0.0 < +0.0
+inline double jmin(double a, double b) { if (a != a) return a; if (b != b) return b; if (a == 0.0 && b == 0.0) return std::signbit(a) ? a : b; return a < b ? a : b; }
+inline double jmax(double a, double b) { if (a != a) return a; if (b != b) return b; if (a == 0.0 && b == 0.0) return std::signbit(a) ? b : a; return a > b ? a : b; }
 struct BoundingBox {
     vec Min, Max, Size;
     bool hasPoint = false;
     void Grow(const vec& mn, const vec& mx) {                                   // GrowToInclude :1612-1627
         if (hasPoint) {
-            Min.x = std::fmin(mn.x, Min.x); Min.y = std::fmin(mn.y, Min.y); Min.z = std::fmin(mn.z, Min.z);
-            Max.x = std::fmax(mx.x, Max.x); Max.y = std::fmax(mx.y, Max.y); Max.z = std::fmax(mx.z, Max.z);
+            Min.x = jmin(mn.x, Min.x); Min.y = jmin(mn.y, Min.y); Min.z = jmin(mn.z, Min.z);
+            Max.x = jmax(mx.x, Max.x); Max.y = jmax(mx.y, Max.y); Max.z = jmax(mx.z, Max.z);
         } else { hasPoint = true; Min = mn; Max = mx; }
         Size = Max.sub(Min);
     }
@@ -131,6 +134,7 @@ struct pts_scene {
     // BVHs
     std::vector<std::unique_ptr<BVH>> sceneObjs;
     int nextBVHId = 0;
+    pts_bvh_builder builder = nullptr; int builderDevice = 0; const char* (*builderError)(void) = nullptr;   // pts_set_bvh_builder
     // packed
     std::vector<float> triBuf, impBuf, ellipBuf, bvhData, mtlBuf;
     std::vector<int32_t> bvhTree, leafTri, objIdx;
@@ -209,8 +213,45 @@ bool splitNode(pts_scene* s, const BoundingBox& bounds, const std::vector<const 
     return true;
 }
 
+// the same object through an external builder (pt_build_bvh): rebuild the node objects from its pre-order arrays
+int buildObjectBVHExternal(pts_scene* s, int start, int end) {
+    const int64_t n = end - start;
+    std::vector<double> tri9((size_t)n * 9);
+    for (int64_t i = 0; i < n; i++) {
+        const triangle& t = s->triangles[(size_t)start + i];
+        double* o = &tri9[(size_t)i * 9];
+        o[0] = t.min.x; o[1] = t.min.y; o[2] = t.min.z; o[3] = t.max.x; o[4] = t.max.y; o[5] = t.max.z; o[6] = t.centroid.x; o[7] = t.centroid.y; o[8] = t.centroid.z;
+    }
+    std::vector<double> bounds((size_t)n * 12); std::vector<int32_t> links((size_t)n * 4), leaf((size_t)n * 4), order((size_t)n);
+    int32_t nNodes = 0, depth = 0;
+    int rc = s->builder(s->builderDevice, tri9.data(), n, &nNodes, bounds.data(), links.data(), leaf.data(), order.data(), &depth);
+    if (rc) return fail(-20, std::string("external BVH builder: ") + (s->builderError ? s->builderError() : "failed"));
+    std::vector<std::unique_ptr<BVH>> nodes((size_t)nNodes);
+    const int idBase = s->nextBVHId;
+    for (int k = nNodes - 1; k >= 0; k--) {                      // children have larger pre-order ids than their parent
+        std::unique_ptr<BVH> b(new BVH());
+        b->ID = idBase + k;
+        b->min = vec(bounds[6 * (size_t)k], bounds[6 * (size_t)k + 1], bounds[6 * (size_t)k + 2]);
+        b->max = vec(bounds[6 * (size_t)k + 3], bounds[6 * (size_t)k + 4], bounds[6 * (size_t)k + 5]);
+        int l = links[2 * (size_t)k], r = links[2 * (size_t)k + 1];
+        if (l >= 0) {
+            if (l <= k || r <= k || l >= nNodes || r >= nNodes || !nodes[(size_t)l] || !nodes[(size_t)r]) return fail(-25, "external BVH builder returned an inconsistent tree");
+            b->Left = std::move(nodes[(size_t)l]); b->Right = std::move(nodes[(size_t)r]);
+        } else {
+            int a = leaf[2 * (size_t)k], e = leaf[2 * (size_t)k + 1];
+            if (a < 0 || e > n || a > e) return fail(-25, "external BVH builder returned an inconsistent leaf range");
+            for (int q = a; q < e; q++) b->storedTri.push_back(s->triangles[(size_t)start + order[(size_t)q]].ID);
+        }
+        nodes[(size_t)k] = std::move(b);
+    }
+    s->nextBVHId += nNodes;
+    s->sceneObjs.push_back(std::move(nodes[0]));
+    return 0;
+}
+
 // BVH(int triIndicesStart, int triIndicesEnd) :1630-1646
 int buildObjectBVH(pts_scene* s, int start, int end) {
+    if (s->builder) return buildObjectBVHExternal(s, start, end);
     std::unique_ptr<BVH> root(new BVH());
     root->ID = s->nextBVHId++;
     BoundingBox bounds;
@@ -480,6 +521,10 @@ int pts_add_object_text(pts_scene* s, const char* obj_text, size_t len, int mate
                         const double rot[3], const char* parent_directory) {
     std::istringstream in(std::string(obj_text, len));
     return parseObj(s, in, material, vec(scale[0], scale[1], scale[2]), vec(shift[0], shift[1], shift[2]), vec(rot[0], rot[1], rot[2]), parent_directory);
+}
+int pts_set_bvh_builder(pts_scene* s, pts_bvh_builder fn, int device, const char* (*last_error)(void)) {
+    s->builder = fn; s->builderDevice = device; s->builderError = last_error;
+    return 0;
 }
 int pts_add_texture(pts_scene* s, const char* path, const char* name) {
     s->textures.push_back(path ? path : ""); s->textureNames.push_back(name ? name : "");

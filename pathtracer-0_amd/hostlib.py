@@ -40,6 +40,7 @@ def _lib():
         L.pts_texture_path.argtypes = [C.c_void_p, C.c_int]; L.pts_texture_path.restype = C.c_char_p
         L.pts_texture_name.argtypes = [C.c_void_p, C.c_int]; L.pts_texture_name.restype = C.c_char_p
         L.pts_parse_mtls.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.pts_set_bvh_builder.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.pts_pack.argtypes = [C.c_void_p]
         L.pts_get_buffer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.pts_count.argtypes = [C.c_void_p, C.c_int]
@@ -73,6 +74,16 @@ class Scene:
         if rc < 0:
             raise RuntimeError(self._L.pts_last_error().decode())
         return rc
+
+    def use_gpu_bvh_builder(self, device=0, enable=True):
+        """Objects added from now on get their BVH from pt_build_bvh (libpt_hip.so, the same tree built on the GPU) instead of the
+        recursive CPU builder.  Fails loudly when the HIP library is missing."""
+        if not enable:
+            self._check(self._L.pts_set_bvh_builder(self._h, None, 0, None))
+            return
+        from . import renderer
+        hip = renderer.lib()
+        self._check(self._L.pts_set_bvh_builder(self._h, C.cast(hip.pt_build_bvh, C.c_void_p), int(device), C.cast(hip.pt_last_error, C.c_void_p)))
 
     def addMaterial(self, name):
         return self._check(self._L.pts_add_material(self._h, name.encode()))

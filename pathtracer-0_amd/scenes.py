@@ -185,6 +185,16 @@ class Workload:
         return Workload(self.name, self.W, self.H, b, self.sky, int(p[4]), int(p[5]), self.info, self.textures)
 
 
+GPU_BVH = None          # set to a device index to build every workload's BVHs with pt_build_bvh (libpt_hip.so) instead of the CPU builder
+
+
+def _new_scene():
+    sc = hostlib.Scene()
+    if GPU_BVH is not None:
+        sc.use_gpu_bvh_builder(GPU_BVH)
+    return sc
+
+
 def _finish(name, sc, W, H, cam, rot, sky_rgb, sample_res, max_bounces, **pk):
     bufs = sc.pack()
     bufs[0] = np.array(cam, dtype=np.float32)
@@ -241,7 +251,7 @@ CORNELL_ROT = (0.0, 0.0, 0.0)
 
 def c1_spheres(W=256, H=256, sample_res=4, max_bounces=4):
     """C1 'built-in sphere scene': 3 addEllipsoid over a ground quad (pattern of dispatch.java:245,264), 1x1 sky."""
-    sc = hostlib.Scene()
+    sc = _new_scene()
     sc.addMaterial("default")
     sc.setLastMtl("Kd", (0.8, 0.8, 0.8))
     sc.setLastMtl("Pr", 1)
@@ -260,7 +270,7 @@ def c1_spheres(W=256, H=256, sample_res=4, max_bounces=4):
 
 def c2_cornell(W=1280, H=720, sample_res=8, max_bounces=8):
     """C2 diffuse-only Cornell box: 5 walls + light quad + 2 boxes = 36 triangles, black 1x1 sky."""
-    sc = hostlib.Scene()
+    sc = _new_scene()
     _cornell_materials(sc)
     o = Obj()
     _cornell_room(o)
@@ -270,7 +280,7 @@ def c2_cornell(W=1280, H=720, sample_res=8, max_bounces=8):
 
 def c3_glass_metal(W=1920, H=1080, sample_res=8, max_bounces=8, subdiv=3):
     """C3: Cornell room + glass and metal icospheres (1280 triangles each at subdiv 3, smooth vn)."""
-    sc = hostlib.Scene()
+    sc = _new_scene()
     _cornell_materials(sc)
     sc.addMaterial("glass")
     sc.setLastMtl("Tr", 0.9)
@@ -297,7 +307,7 @@ def c3_glass_metal(W=1920, H=1080, sample_res=8, max_bounces=8, subdiv=3):
 def c4_mesh(W=1920, H=1080, sample_res=8, max_bounces=8, nu=224, nv=224, seed=4):
     """C4: Cornell room + one seeded displaced-torus mesh of 2*nu*nv (= 100 352) triangles in ONE `o` group
     (one BVH, like the reference's single-object dragon, dispatch.java:257)."""
-    sc = hostlib.Scene()
+    sc = _new_scene()
     _cornell_materials(sc)
     sc.addMaterial("clay")
     sc.setLastMtl("Kd", (0.7, 0.55, 0.4))
@@ -321,7 +331,7 @@ def c4_mesh(W=1920, H=1080, sample_res=8, max_bounces=8, nu=224, nv=224, seed=4)
 
 def c5_clearcoat_sss(W=3840, H=2160, sample_res=8, max_bounces=16, subdiv=4):
     """C5: Cornell room + clearcoat and subsurface meshes, plus the reference's "test" material (dispatch.java:228-239)."""
-    sc = hostlib.Scene()
+    sc = _new_scene()
     _cornell_materials(sc)
     sc.addMaterial("coat")
     sc.setLastMtl("Kd", (0.1, 0.2, 0.7))
@@ -381,7 +391,7 @@ def t1_textured(W=96, H=54, sample_res=8, max_bounces=8):
         3: tex(5, 7, lambda i, j: tuple(int(v) for v in rs.randint(0, 256, 3))),                              # noise (Ks / Pr / Pm / Pc / Tr source)
         4: tex(2, 2, lambda i, j: (60, 230, 90)),                                                             # "normal" texels, used raw (frag.glsl:827)
     }
-    sc = hostlib.Scene()
+    sc = _new_scene()
     _cornell_materials(sc)
     sc.addMaterial("floor"); sc.setLastMtl("Kd", (0.9, 0.9, 0.9)); sc.setLastMtl("Pr", 1); sc.setLastMtl("map_Kd", 1)
     sc.addMaterial("glow"); sc.setLastMtl("Kd", (0.5, 0.5, 0.5)); sc.setLastMtl("Pr", 1); sc.setLastMtl("map_Ke", 2); sc.setLastMtl("map_Ks", 3); sc.setLastMtl("Pc", 0.3)
@@ -419,7 +429,7 @@ def asset_workload(directory, W, H, cam=CORNELL_CAM, rot=CORNELL_ROT, sky=(30, 4
     """The reference's way of loading a model (dispatch.java:219-229 + :869-882): texture 0 is the sky, then
     scene.addObject(<directory>) parses every .mtl (registering the map files) and every .obj in it; the decoded images fill
     the rest of the texture table.  `sky` is an RGB triple or a path to an image."""
-    sc = hostlib.Scene()
+    sc = _new_scene()
     sky_img = sky
     if isinstance(sky, str):
         from PIL import Image

@@ -463,6 +463,57 @@ def test_n3_asset_directory(pt, oracle, renderer_mod, tmp_path):
     assert got[..., :3].max() > 0
 
 
+# ---- the BVH builder on the GPU (pt_build_bvh) against the CPU mirror of the Java builder
+@pytest.mark.parametrize("name", ["C2", "C3", "C4", "C5"])
+def test_gpu_bvh_builder_equals_cpu_builder(pt, name):
+    cpu = pt.scenes.build(name, 64, 36)
+    pt.scenes.GPU_BVH = 0
+    try:
+        gpu = pt.scenes.build(name, 64, 36)
+    finally:
+        pt.scenes.GPU_BVH = None
+    assert gpu.info == cpu.info
+    for b in (3, 10, 11, 12, 13):
+        assert np.array_equal(cpu.buffers[b].view(np.uint32), gpu.buffers[b].view(np.uint32)), b
+
+
+def _soup_obj(rs, n, degenerate=0.0):
+    """n random small triangles in the unit cube; a fraction share one centroid (leaves with several triangles)"""
+    lines = ["o soup", "vn 0 0 1"]
+    k = 0
+    for i in range(n):
+        c = rs.rand(3) if rs.rand() >= degenerate else np.array([0.5, 0.5, 0.5])
+        d = (rs.rand(3, 3) - 0.5) * 0.05
+        d -= d.mean(axis=0)                                        # exact-ish common centroid for the degenerate ones
+        for v in c + d:
+            lines.append("v %.17g %.17g %.17g" % tuple(v))
+        lines.append("f %d//1 %d//1 %d//1" % (k + 1, k + 2, k + 3))
+        k += 3
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("n,degenerate,seed", [(2, 0.0, 1), (3, 0.0, 2), (65, 0.0, 3), (64, 0.5, 4), (1000, 0.0, 5), (5000, 0.3, 6), (40000, 0.02, 7)])
+def test_gpu_bvh_builder_random_soups(pt, n, degenerate, seed):
+    text = _soup_obj(np.random.RandomState(seed), n, degenerate)
+    out = []
+    for gpu in (False, True):
+        sc = pt.hostlib.Scene(); sc.addMaterial("m")
+        if gpu:
+            sc.use_gpu_bvh_builder(0)
+        sc.addObjectText(text, 0)
+        sc.addObjectText(text, 0, shift=(2.0, 0.0, 0.0))          # a second object: ids and leaf offsets continue
+        out.append((sc.pack(), {k: sc.count(k) for k in ("nodes", "objects", "max_depth", "max_leaf", "leaf_indices")}))
+    assert out[0][1] == out[1][1]
+    for b in (3, 10, 11, 12, 13):
+        assert np.array_equal(out[0][0][b].view(np.uint32), out[1][0][b].view(np.uint32)), b
+
+
+def test_gpu_bvh_builder_errors(pt):
+    sc = pt.hostlib.Scene(); sc.addMaterial("m"); sc.use_gpu_bvh_builder(0)
+    with pytest.raises(RuntimeError, match="Q-16"):
+        sc.addObjectText("o one\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n", 0)
+
+
 def test_n3_missing_texture_and_mapped_ellipsoid_are_errors(pt, renderer_mod):
     wl = pt.scenes.build("T1", 64, 36)
     r = renderer_mod.Renderer(64, 36)
