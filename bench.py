@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--extend-tpb", type=int, default=None)
     ap.add_argument("--extend-cache", type=int, default=None)
     ap.add_argument("--refill-min", type=int, default=None)
+    ap.add_argument("--none-min", type=int, default=None)
     ap.add_argument("--extend-blocks-per-cu", type=int, default=None)
     ap.add_argument("--inner-keep", type=int, default=None)
     ap.add_argument("--rehearse-shard", type=int, nargs=2, metavar=("RANK", "COUNT"), default=None,
@@ -84,7 +85,7 @@ def main():
         r.set_option("path_slots", args.path_slots)
     if args.lds_budget is not None:
         r.set_option("lds_budget", args.lds_budget)
-    for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min),
+    for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min), ("none_min", args.none_min),
                       ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep)):
         if val is not None:
             r.set_option(name, val)

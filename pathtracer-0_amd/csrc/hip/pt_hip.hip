@@ -63,6 +63,7 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned oldestBusy;    // k_scan_inflight: a live slot still works on the oldest unaccumulated batch
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
     unsigned qCount[64];    // entries of queue (j&1) at [32*(j&1)]: two words, 128 B apart
+    unsigned long long dbg[16];  // developer build (-DPT_PHASE_STATS): trips and active lanes per phase of the intersect kernel
 };
 __device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return ctl->exhausted[(iter + 3) & 3] != 0; }
 
@@ -262,7 +263,7 @@ constexpr int CUR_IDLE = 0x7fffffff;
 
 template <bool COUNT, typename StackT, int TPB>
 __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
-                                                       Control* ctl, int refillMin, int keepEighths, int nObjLds) {
+                                                       Control* ctl, int refillMin, int keepEighths, int nObjLds, int noneMin) {
     extern __shared__ float4 smem[];
     float4* ldsN = smem;
     float4* ldsT = smem + 4 * sc.ldsNodes;
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->qCount[32 * ((iter + 1) & 1)] = 0;     // cursor of the queue this iteration's shading may write
     const int lane = threadIdx.x & 63;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
-    const unsigned nWaves = gridDim.x * (TPB / 64), waveId = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const unsigned nWaves = gridDim.x * (TPB / 64), waveId = __builtin_amdgcn_readfirstlane(blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));   // scalar: pos/end live in SGPRs
     const unsigned per = (((n + nWaves - 1) / nWaves) + 63u) & ~63u;       // static range of this wave, 64-aligned -> coalesced first fill
     unsigned pos = waveId * per;
     const unsigned end = min(pos + per, n);
@@ -288,11 +289,19 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     bool probe = false;
     unsigned slot = 0;
     Counters c;
+#ifdef PT_PHASE_STATS
+    unsigned long long ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // {trips, active lanes} x {refill, next-object/retire, inner, leaf}, outer trips, live lanes at outer trips
+#define PS(k, lanes) do { ps[2 * (k)]++; ps[2 * (k) + 1] += (unsigned long long)(lanes); } while (0)
+#else
+#define PS(k, lanes) do { } while (0)
+#endif
     for (;;) {
         // ---- refill idle lanes from the wave's range
         unsigned long long idle = __ballot(cur == CUR_IDLE);
         int nIdle = __popcll(idle);
+        PS(4, 64 - nIdle);
         if (pos < end && nIdle >= refillMin) {                              // wave-uniform
+            PS(0, min(nIdle, (int)(end - pos)));
             if (cur == CUR_IDLE) {
                 unsigned q = pos + (unsigned)__popcll(idle & ltMask);
                 if (q < end) {
@@ -307,9 +316,13 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                         ob = probe ? (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK) : 0;
                         obEnd = probe ? ob + 1 : sc.numObj;
                         closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; sp = 0; cur = CUR_NONE;
-                        for (int k = 0; k < nObjLds; k++) {
-                            const ObjRoot R = sc.roots[k];
-                            rootDist[k * TPB] = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]);
+                        for (int k = 0; k < nObjLds; k += 2) {              // two root boxes per packed-f32 test, like the two children of a node
+                            const ObjRoot A = sc.roots[k], B = sc.roots[min(k + 1, nObjLds - 1)];
+                            float da, db;
+                            rayBox2(o, invD, make_float4(A.bmin[0], B.bmin[0], A.bmin[1], B.bmin[1]), make_float4(A.bmin[2], B.bmin[2], A.bmax[0], B.bmax[0]),
+                                    make_float4(A.bmax[1], B.bmax[1], A.bmax[2], B.bmax[2]), da, db);
+                            rootDist[k * TPB] = da;
+                            if (k + 1 < nObjLds) rootDist[(k + 1) * TPB] = db;
                         }
                     }
                 }
@@ -318,8 +331,14 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
             nIdle = __popcll(__ballot(cur == CUR_IDLE));
         }
         if (nIdle == 64) { if (pos >= end) break; continue; }
-        // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire
-        if (__any(cur == CUR_NONE)) {
+        // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire.  Like the two traversal
+        // phases below this one is worth a trip only for enough lanes: it runs when noneMin lanes wait for it, or when it is the
+        // most wanted of the three
+        int nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
+        int nLeaf = __popcll(__ballot(cur < 0));
+        const int nNone = __popcll(__ballot(cur == CUR_NONE));
+        if (nNone >= noneMin || (nNone > 0 && nNone >= nInner && nNone >= nLeaf)) {
+            PS(1, nNone);
             if (cur == CUR_NONE) {
                 while (ob < obEnd) {
                     float rd;
@@ -349,13 +368,14 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                     cur = CUR_IDLE;
                 }
             }
+            nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));
+            nLeaf = __popcll(__ballot(cur < 0));
         }
-        int nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
-        const int nLeaf = __popcll(__ballot(cur < 0));
         if (nInner >= nLeaf && nInner > 0) {
             // ---- inner-node steps (:521-532); repeated while most of the lanes that started the phase still sit on inner nodes
             const int keepGoing = (nInner * keepEighths) >> 3;
             do {
+                PS(2, nInner);
                 if ((unsigned)cur < (unsigned)CUR_NONE) {
                     float4 q0, q1, q2, q3;
                     loadNode(sc, ldsN, cur, q0, q1, q2, q3);
@@ -388,6 +408,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
             const int keepGoing = (nLeaf * keepEighths) >> 3;
             int nMore;
             do {
+                PS(3, __popcll(__ballot(cur < 0)));
                 bool more = false;
                 if (cur < 0) {
                     int ti = -(cur + 1);
@@ -419,6 +440,10 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
         atomicAdd(&ctl->cnt[PT_CNT_HITUPD], (unsigned long long)c.hitupd);
         atomicAdd(&ctl->cnt[PT_CNT_BOXTESTS], (unsigned long long)c.boxtests);
     }
+#ifdef PT_PHASE_STATS
+    if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd(&ctl->dbg[k], ps[k]);
+#endif
+#undef PS
 }
 
 // trace() loop body + sample/job bookkeeping for every live path slot.
@@ -727,7 +752,8 @@ struct pt_ctx {
     int ldsBudget = 20 * 1024;
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
     int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
-    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 3; int innerKeepEighths = 6;
+    int noneMin = 16;               // lanes waiting for their next object / retirement that make that phase worth a trip
+    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 4; int innerKeepEighths = 6;
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
 };
@@ -993,7 +1019,7 @@ template <bool COUNT, typename StackT, int TPB>
 void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int grid) {
     int nObjLds = std::min(sc.numObj, 8);
     hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
-                       c->innerKeepEighths, nObjLds);
+                       c->innerKeepEighths, nObjLds, c->noneMin);
 }
 void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     const int launched = (int)pr.launched;
@@ -1476,7 +1502,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 0: if (value != 0 && (value < BLOCK || value > (1 << 26))) return fail(PT_ERR_ARG, "path slots must be 0 (automatic) or in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
         case 1: c->countStats = value != 0; return PT_OK;
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
-        case 3: return PT_OK;      // (was: host-side compaction threshold; the tail is packed on the device now) accepted, ignored
+        case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; return PT_OK;
         case 4: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "extend mode must be 0 or 1"); c->extendMode = (int)value; return PT_OK;
         case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
@@ -1507,8 +1533,20 @@ int pt_reset_counters(pt_ctx* c) {
     { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemset(c->dCtl->cnt, 0, sizeof(Control::cnt)));
+    HIP_TRY(hipMemset(c->dCtl->dbg, 0, sizeof(Control::dbg)));
     std::memset(c->hostCnt, 0, sizeof(c->hostCnt));
     for (auto& k : c->kt) { k.used = 0; k.ms = 0; k.launches = 0; k.each.clear(); }
+    return PT_OK;
+}
+
+int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
+    if (!c || !out) return fail(PT_ERR_ARG, "pt_debug_phase_stats: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    Control h;
+    HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < n && k < 16; k++) out[k] = h.dbg[k];
     return PT_OK;
 }
 
