@@ -502,6 +502,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     // DISTANCE_TRAVELED (G5) when the transmission lobe won; index-stack slots 4-7 / 8-9 (S1/S2) are not even fetched
     // unless the stack is that deep (push/pop never touch slots above the current size, frag.glsl:142-158).
     bool touchS1 = false, touchS2 = false, sampleDone = false, newJob = false, isProbe = false;
+    float4 g3in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) {
         // every load of the segment is issued here, in one batch (the flags came through LDS): the kernel's critical path
         // is memory round trips, not bytes
@@ -513,13 +514,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             touchS1 = p.stackSize >= 4; touchS2 = p.stackSize >= 8;
             if (touchS1) s1 = st.S1[i];
             if (touchS2) s2 = st.S2[i];
-            g5 = st.G5[i];
+            // RAY_ENTER_LOCATION / DISTANCE_TRAVELED are read only while the path is inside a medium or owes an absorption term;
+            // a transmission event on any other path fetches them late (shadeSegment), which is rare
+            p.g5loaded = p.inObj || p.applyAbs;
+            if (p.g5loaded) g5 = st.G5[i];
         }
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
         p.col = v3(g2.x, g2.y, g2.z); p.pix = __float_as_uint(g2.w);
         p.inc = v3(g3.x, g3.y, g3.z); p.fi = __float_as_uint(g3.w);
         p.sum = v3(g4.x, g4.y, g4.z); p.ls = __float_as_uint(g4.w);
-        p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; p.g5dirty = false;
+        p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5dirty = false;
+        if (!TRANS) p.g5loaded = true;
+        g3in = g3;
         p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
         isProbe = DIRECT && p.probe;
         if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w));      // RAYTRACING == 0 (frag.glsl:911-912)
@@ -593,7 +599,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
         }
         st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.pix));
-        st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
+        {   // incoming light changes only at emitters, at the sky and at sample boundaries: most segments leave the group as it was
+            const float4 g3out = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
+            if (__float_as_uint(g3out.x) != __float_as_uint(g3in.x) || __float_as_uint(g3out.y) != __float_as_uint(g3in.y) ||
+                __float_as_uint(g3out.z) != __float_as_uint(g3in.z) || __float_as_uint(g3out.w) != __float_as_uint(g3in.w)) st.G3[i] = g3out;
+        }
         if (sampleDone) st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.ls));
         if (TRANS) {
             st.S0[i] = make_float4(p.s[0], p.s[1], p.s[2], p.s[3]);

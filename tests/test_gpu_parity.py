@@ -236,6 +236,37 @@ def test_full_size_properties_c3(pt, oracle, renderer_mod):
     assert np.array_equal(a[::27, ::24], ref[::27, ::24])
 
 
+def test_full_size_c1_whole_image(pt, oracle, renderer_mod):
+    """BASELINE.json configs[0] (C1: 256x256, SAMPLE_RES 4, 1 frame, 4 bounces, ellipsoids + ground quad) in full: every pixel against the oracle"""
+    cfg = pt.scenes.CONFIGS["C1"]
+    wl = pt.scenes.build("C1", cfg["W"], cfg["H"])
+    assert (wl.sample_res, wl.max_bounces) == (4, 4)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, cfg["spp"] // cfg["sample_res"])
+    assert_same(got, ref, cnt, ocnt)
+
+
+def test_full_size_c2_lattice_and_display(pt, oracle, renderer_mod):
+    """BASELINE.json configs[1] (C2: 1280x720, 64 spp = 8 frames x 8, Cornell box) in full: oracle on a pixel lattice, and the 8-bit display
+    image of the whole frame derived from the same accumulator"""
+    cfg = pt.scenes.CONFIGS["C2"]
+    W, H = cfg["W"], cfg["H"]
+    wl = pt.scenes.build("C2", W, H)
+    n = cfg["spp"] // cfg["sample_res"]
+    seeds = seeds_for(pt, 1, n)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds)
+    a = r.read_frame().copy()
+    disp = r.read_display(n, java_bytes=False)
+    r.close()
+    sc = oracle.Scene.from_workload(wl)
+    ref = np.zeros((H, W, 4), np.float32)
+    for i, sd in enumerate(seeds):
+        oracle.render(sc, W, H, 1 + i, sd, ref, nthreads=8, xs=16, ys=18)
+    assert np.array_equal(a[::18, ::16], ref[::18, ::16])
+    assert np.all(a[..., 3] == n)
+    assert np.array_equal(disp, oracle.display(a, n, java_bytes=False))
+
+
 @pytest.mark.parametrize("name,xs,ys", [("C4", 24, 27), ("C5", 48, 54)])
 def test_full_size_properties_c4_c5(pt, oracle, renderer_mod, name, xs, ys):
     """BASELINE.json's full C4 (1920x1080, one 100k-triangle BVH) and C5 (3840x2160, 16 bounces) sizes: the overlapped schedule and a
