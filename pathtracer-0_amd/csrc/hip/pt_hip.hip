@@ -697,8 +697,8 @@ __global__ void k_submit(Control* ctl, unsigned addJobs, int streamStart, unsign
     for (int k = 0; k < 4; k++) { dry = dry || ctl->exhausted[k] != 0; ctl->exhausted[k] = 0; }
     if (ctl->nextJob > ctl->jobEnd) { ctl->nextJob = ctl->jobEnd; dry = true; }
     ctl->jobEnd += addJobs;
-    ctl->needRevive = dry ? 1u : 0u;
-    if (streamStart) { ctl->needRevive = 2u; ctl->nextJob = min(nSlots, addJobs); }      // fresh pool: slot i starts job i, no pulling
+    ctl->needRevive = (dry || streamStart == 2) ? 1u : 0u;                              // 2: the pool has just grown by dead slots
+    if (streamStart == 1) { ctl->needRevive = 2u; ctl->nextJob = min(nSlots, addJobs); }      // fresh pool: slot i starts job i, no pulling
     ctl->qCount[0] = 0; ctl->qCount[32] = 0;
 }
 
@@ -987,13 +987,14 @@ int buildScene(pt_ctx* c) {
     return 0;
 }
 
-int ensurePool(pt_ctx* c) {
-    if (c->allocSlots >= c->poolActive && c->allocTrans == c->trans) return 0;
+int ensurePool(pt_ctx* c, int capacity) {               // capacity >= poolActive: room for a pool that grows while a stream runs
+    capacity = std::max(capacity, c->poolActive);
+    if (c->allocSlots >= capacity && c->allocTrans == c->trans) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H};
     for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
     for (unsigned** q : {&c->dQueue[0], &c->dQueue[1]}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
-    size_t n = (size_t)c->poolActive;
+    size_t n = (size_t)capacity;
     for (int k = 0; k < 10; k++) {
         bool transOnly = (k >= 5 && k <= 8);
         if (transOnly && !c->trans) continue;
@@ -1001,7 +1002,7 @@ int ensurePool(pt_ctx* c) {
     }
     HIP_TRY(hipMalloc((void**)&c->dQueue[0], n * 4));
     HIP_TRY(hipMalloc((void**)&c->dQueue[1], n * 4));
-    c->allocSlots = c->poolActive; c->allocTrans = c->trans;
+    c->allocSlots = capacity; c->allocTrans = c->trans;
     return 0;
 }
 
@@ -1104,7 +1105,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (c->pending.empty()) return true;
         switch (until) {
             case PUMP_IDLE: return false;
-            case PUMP_ISSUED: return c->draining || (int64_t)c->streamJobs - (int64_t)c->lastNextJob <= (int64_t)c->lastDelta;
+            case PUMP_ISSUED: return c->draining || (int64_t)c->streamJobs - (int64_t)c->lastNextJob <= std::max<int64_t>((int64_t)c->lastDelta, (int64_t)arg);
             case PUMP_IMAGE: for (const auto& e : c->pending) if (e.image == arg) return false; return true;
             case PUMP_RING: return (int)(c->streamFrames - c->pending.front().f0) <= arg;
         }
@@ -1115,7 +1116,9 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + (uint64_t)N;
     const uint64_t maxIters = 2 * ((outstanding + N - 1) / N + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
     uint64_t iters = 0;
-    while (!satisfied()) {
+    bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going with one group of iterations
+    while (kick || !satisfied()) {
+        kick = false;
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
         // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
         // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
@@ -1123,9 +1126,9 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         // every 24 iterations, in the tail every 8; each look shrinks the launch grids to the live count.
         int CHECK = c->draining ? 8 : 24;
         if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
-            int64_t left = (int64_t)c->streamJobs - (int64_t)c->lastNextJob - (int64_t)c->lastDelta / 2;
+            int64_t left = (int64_t)c->streamJobs - (int64_t)c->lastNextJob - (int64_t)c->lastDelta / 2 - (int64_t)arg;
             int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));
-            CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, left / perIter));
+            if (left > 0) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, left / perIter));
         }
         for (int k = 0; k < CHECK; k++) {
             PoolRun pr; pr.stream = s; pr.st = c->st; pr.launched = c->launched; pr.iter = c->iter;
@@ -1199,7 +1202,13 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     FrameIn fin;
     std::memcpy(fin.params, P, 48); std::memcpy(fin.origin, c->origin.data(), 12); std::memcpy(fin.rotation, c->rotation.data(), 12); std::memcpy(fin.mouse, c->mouse.data(), 12);
     // the running stream can take this batch if nothing the kernels were launched with changes
-    const int wantRing = (async ? pt_ctx::IMAGES : 1) * nFrames;      // overlapped: room for the batches of as many images as can be pending
+    // overlapped: room for the batches of as many images as can be pending, and for callers that submit frame by frame to run
+    // ahead (at least 64 rows while they stay below 8 GB)
+    int wantRing = nFrames;
+    if (async) {
+        const size_t rowBytes = (size_t)c->nSlotsImg * 16;
+        wantRing = std::max(pt_ctx::IMAGES * nFrames, (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)8 << 30) / rowBytes)));
+    }
     bool join = !c->pending.empty() && !c->sceneDirty && std::memcmp(&fin, &c->streamIn, sizeof(FrameIn)) == 0 && c->ringFrames >= wantRing &&
                 (uint64_t)c->streamJobs + nJobs64 < (1ull << 31);
     if (!join && (rc = flushStream(c))) return rc;
@@ -1215,7 +1224,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
             size_t want = std::min<size_t>(std::max<size_t>(async ? nJobs64 * 3 / 8 : nJobs64 / 5, (size_t)1 << 20), (size_t)1 << (async ? 23 : 22));
             c->poolActive = (int)((std::min<size_t>(want, std::max<size_t>(nJobs64, BLOCK)) + BLOCK - 1) / BLOCK * BLOCK);
         }
-        if ((rc = ensurePool(c))) return rc;
+        if ((rc = ensurePool(c, (async && c->poolSlots == 0) ? (1 << 23) : 0))) return rc;
         if (c->ringFrames < wantRing) {
             HIP_TRY(hipStreamSynchronize(s));
             if (c->dColbuf) HIP_TRY(hipFree(c->dColbuf));
@@ -1237,6 +1246,18 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         if ((rc = pump(c, PUMP_RING, c->ringFrames - nFrames))) return rc;        // wait for ring rows
         if (c->pending.empty()) return submitBatch(c, firstFrame, nFrames, seeds, async);   // the stream ended meanwhile: start over
     }
+    // a stream fed in small batches (the reference draws ONE frame per call) started with a small pool: let it grow with the backlog
+    bool grown = false;
+    if (join && async && c->poolSlots == 0) {
+        const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + nJobs64;
+        size_t target = std::min<size_t>(std::max<size_t>(outstanding * 3 / 8, (size_t)1 << 20), (size_t)1 << 23);
+        target = std::min<size_t>((target + BLOCK - 1) / BLOCK * BLOCK, (size_t)c->allocSlots);
+        if (target > (size_t)c->poolActive + (size_t)c->poolActive / 4) {
+            HIP_TRY(hipMemsetAsync(c->st.G1 + c->poolActive, 0, (target - (size_t)c->poolActive) * 16, s));      // the new slots are dead
+            c->poolActive = (int)target;
+            grown = true;
+        }
+    }
     // ---- append
     const unsigned f0 = c->streamFrames;
     for (int f = 0; f < nFrames; f++) c->hSeeds[(f0 + (unsigned)f) % (unsigned)c->ringFrames] = seeds[f];
@@ -1245,7 +1266,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         HIP_TRY(hipMemcpyAsync(c->dSeeds + r0, c->hSeeds + r0, (size_t)n0 * 4, hipMemcpyHostToDevice, s));
         if (n0 < (unsigned)nFrames) HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)(nFrames - n0) * 4, hipMemcpyHostToDevice, s));
     }
-    hipLaunchKernelGGL(k_submit, dim3(1), dim3(1), 0, s, c->dCtl, (unsigned)nJobs64, join ? 0 : 1, (unsigned)c->poolActive);
+    hipLaunchKernelGGL(k_submit, dim3(1), dim3(1), 0, s, c->dCtl, (unsigned)nJobs64, join ? (grown ? 2 : 0) : 1, (unsigned)c->poolActive);
     const Batch b = streamBatch(c);
     const int N = c->poolActive;
     if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<true>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
@@ -1255,7 +1276,8 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     c->pending.push_back(e);
     c->draining = false; c->launched = (unsigned)N;              // (if the pool had run dry, k_submit dropped the tail queue)
     HIP_TRY(hipGetLastError());
-    if (async) return pump(c, PUMP_ISSUED, 0);
+    // asynchronous: come back while the backlog of jobs not yet handed out is below what keeps the largest pool fed (2^23 * 8/3)
+    if (async) return pump(c, PUMP_ISSUED, c->poolSlots == 0 ? 22000000 : 0);
     return pump(c, PUMP_IDLE, 0);
 }
 
