@@ -70,7 +70,7 @@ int pt_reset_frame(pt_ctx* ctx);
 
 /* One frame: glUniform1i(u_frameCount), glUniform1i(u_seed), glDrawArrays(GL_TRIANGLES,0,6)
  *                                                                  dispatch.java:697-705
- * Asynchronous on the context's stream. */
+ * On return the frame is accumulated in FRAME (in stream order on the context's stream). */
 int pt_render(pt_ctx* ctx, int frame_count, int seed);
 /* n_frames consecutive frames (u_frameCount = first_frame .. first_frame+n_frames-1, u_seed =
  * seeds[i]) rendered as ONE wavefront batch; FRAME is accumulated in frame order, so the result
@@ -78,9 +78,9 @@ int pt_render(pt_ctx* ctx, int frame_count, int seed);
 int pt_render_batch(pt_ctx* ctx, int first_frame, int n_frames, const int32_t* seeds);
 
 /* ---- overlapped batches (no reference counterpart: the GL driver pipelines the reference's draw calls by itself) ----
- * pt_render_batch_async submits a batch like pt_render_batch but returns once most of its pixel-frame jobs have been handed
- * to path slots; the rest, and the paths still in flight, finish underneath the next batch, so the path pool never drains
- * between batches.  Batches overlap as long as the frame inputs (bindings 0, 1, 2, 4) and the scene are unchanged; a change
+ * pt_render_batch_async submits a batch like pt_render_batch, gets the GPU going and returns while jobs are still waiting to
+ * be handed to path slots (at most ~22 M of them) and paths are in flight; they finish underneath the next batch, so the
+ * path pool never drains between batches (and, fed frame by frame, grows with the backlog).  Batches overlap as long as the frame inputs (bindings 0, 1, 2, 4) and the scene are unchanged; a change
  * finishes the running work first.  Frames are still added to the FRAME image in u_frameCount order, bit-identical to the
  * synchronous calls.  Every other entry point that reads or modifies results (pt_read_frame, pt_read_display,
  * pt_synchronize, pt_reset_frame, pt_get_counters, pt_set_option, ...) completes all submitted batches first. */
@@ -136,8 +136,9 @@ int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_nodes, double* node_bounds, int32_t* node_links,
                  int32_t* node_leaf, int32_t* leaf_tris, int32_t* max_depth);
 
-/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: jobs/5 clamped to [2^20, 2^22]), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the
- * simple intersect kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 16; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
+/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 3/8 of the
+ * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
+ * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 16; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on resident persistent blocks per CU (default 4; 0 = as many as LDS allows),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
@@ -150,8 +151,8 @@ enum { PT_CNT_SEGMENTS = 0, PT_CNT_NODES, PT_CNT_TRITESTS, PT_CNT_HITUPD, PT_CNT
 int pt_get_counters(pt_ctx* ctx, uint64_t* out, int n);
 int pt_reset_counters(pt_ctx* ctx);
 
-/* Per-kernel device time of the last pt_render/pt_render_batch, measured with HIP events on the
- * launch stream: kernel 0 = intersect (extend), 1 = shade, 2 = generate, 3 = accumulate.
+/* Per-kernel device time since pt_set_timing(1) / pt_reset_counters, measured with HIP events on the
+ * launch stream: kernel 0 = intersect (extend), 1 = shade, 2 = pool start (revive), 3 = accumulate.
  * Synchronises.  launches = number of launches, total_ms = summed duration. */
 int pt_kernel_time(pt_ctx* ctx, int kernel, int64_t* launches, double* total_ms);
 int pt_set_timing(pt_ctx* ctx, int enabled);
