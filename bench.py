@@ -222,7 +222,12 @@ def main():
                            "whole_path_GBps": round(bytes_per_sample * value * 1e6 / 1e9 / world, 1),
                            "median_launch_ms": round(r.kernel_time_median("extend"), 4), "shade_median_launch_ms": round(r.kernel_time_median("shade"), 4),
                            "shade_avg_launch_ms": round(ms_sh / max(n_sh, 1), 4), "extend_share_of_step": round(ms_ext / (dt * 1e3), 3),
-                           "shade_share_of_step": round(ms_sh / (dt * 1e3), 3)}
+                           "shade_share_of_step": round(ms_sh / (dt * 1e3), 3),
+                           "measured_hbm_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
+                           "note": "achieved = SURVEY.md 8(d) algorithmic bytes (the reference's 44 B per node visit, 36 B per triangle test, 124 B per hit "
+                                   "update, 44 B of ray/hit queue) / launch time; the device-private BVH is served from LDS and L2, so HBM moves only "
+                                   "`traffic` bytes per launch (PMC) and a fraction above 1 means the kernel beats what streaming the reference layout "
+                                   "from HBM would allow; its own limiter is instruction issue and load latency at 8 waves per SIMD (DESIGN.md 2)"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the reference has no CPU render path: the timed CPU baseline is the oracle ("port")
