@@ -300,11 +300,12 @@ def test_full_size_properties_c4_c5(pt, oracle, renderer_mod, name, xs, ys):
     assert np.array_equal(a[::ys, ::xs], ref[::ys, ::xs])
 
 
-@pytest.mark.parametrize("slots,batch", [(2048, 3), (1 << 16, 1), (4096, 6)])
+@pytest.mark.parametrize("slots,batch", [(2048, 3), (1 << 16, 1), (4096, 6), (0, 1), (0, 2)])
 def test_overlapped_batches_equal_synchronous(pt, oracle, renderer_mod, slots, batch):
     """pt_render_batch_async / pt_next_image / pt_finish_image: consecutive batches share one running path pool (no drain between
     them; with (65536, 1) the pool is larger than a batch and runs dry in between, so dead slots are revived) - same bits as the
-    synchronous calls, image after image"""
+    synchronous calls, image after image.  slots 0 = automatic: the pool starts at the size of the first small batch and grows with
+    the backlog of the following submissions"""
     import torch
     from pathtracer_0_amd import shard
     W, H = 128, 72
@@ -312,7 +313,8 @@ def test_overlapped_batches_equal_synchronous(pt, oracle, renderer_mod, slots, b
     sc = oracle.Scene.from_workload(wl)
     dev = torch.device("cuda", 0)
     r = renderer_mod.Renderer(W, H)
-    r.set_option("path_slots", slots)
+    if slots:
+        r.set_option("path_slots", slots)
     r.set_option("count_stats", 1)
     r.load_workload(wl)
     images = []
