@@ -104,15 +104,9 @@ def main():
     # a step's last paths finish underneath the next step's first ones (pt_render_batch_async / pt_next_image), and its
     # image is gathered while the next one renders.  Every step's work and gather lie inside the timed region; the fence
     # completes everything that is still in flight.
-    LAG = 2                     # an image is gathered two steps after it was submitted: by then its last paths have long retired
-    in_flight = [0]
+    pipeline = shard.StepPipeline(r, unshard, dev, lag=2)      # an image is gathered two steps after it was submitted
 
-    def step():
-        out = None
-        if args.sync:
-            r.reset_frame()
-        else:
-            r.next_image()
+    def submit():
         done = 0
         while done < fps:
             n = min(MAX_BATCH, fps - done)
@@ -123,22 +117,17 @@ def main():
             else:
                 r.render_batch_async(first, seeds)
             done += n
+
+    def step():
         if args.sync:
+            r.reset_frame()
+            submit()
             return shard.gather_frame(shard.frame_tensor(r, dev), unshard, dst=0)
-        if in_flight[0] == LAG:
-            r.finish_image(LAG)
-            out = shard.gather_frame(shard.frame_tensor(r, dev, age=LAG), unshard, dst=0)
-        else:
-            in_flight[0] += 1
-        return out
+        return pipeline.step(submit)
 
     def drain():
-        out = None
-        while in_flight[0] > 0:
-            in_flight[0] -= 1
-            r.finish_image(in_flight[0])
-            out = shard.gather_frame(shard.frame_tensor(r, dev, age=in_flight[0]), unshard, dst=0)
-        return out
+        imgs = pipeline.drain()
+        return imgs[-1] if imgs else None
 
     def fence():
         r.synchronize()

@@ -62,3 +62,36 @@ def gather_frame(packed, unsharder, dst=0, group=None):
         return unsharder(gathered.reshape(-1, 4))
     dist.gather(packed, None, dst=dst, group=group)
     return None
+
+
+class StepPipeline:
+    """bench.py's schedule for consecutive images: every step starts a new image (pt_next_image) and submits its batches
+    asynchronously; the image is completed and gathered LAG steps later, when its last paths have long retired, so neither the
+    path pool nor the collective ever waits for a straggler.  `drain()` completes and gathers what is still in flight."""
+
+    def __init__(self, renderer, unsharder, device, lag=2, dst=0, group=None, tensor_of=None):
+        assert 0 <= lag <= 3, "the library keeps a ring of four FRAME images"
+        self.r, self.unsharder, self.device, self.lag, self.dst, self.group = renderer, unsharder, device, lag, dst, group
+        self.tensor_of = tensor_of or (lambda r, age: frame_tensor(r, device, age))
+        self.in_flight = 0
+
+    def _collect(self, age):
+        self.r.finish_image(age)
+        return gather_frame(self.tensor_of(self.r, age), self.unsharder, dst=self.dst, group=self.group)
+
+    def step(self, submit):
+        """submit(): the step's pt_render_batch_async calls.  Returns the gathered image of the step LAG steps ago (rank dst), else None."""
+        self.r.next_image()
+        submit()
+        if self.in_flight == self.lag:
+            return self._collect(self.lag)
+        self.in_flight += 1
+        return None
+
+    def drain(self):
+        """-> the gathered images still in flight, oldest first"""
+        out = []
+        while self.in_flight > 0:
+            self.in_flight -= 1
+            out.append(self._collect(self.in_flight))
+        return out
