@@ -138,7 +138,7 @@ int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_node
 
 /* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 3/8 of the
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
- * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 16; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
+ * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on resident persistent blocks per CU (default 4; 0 = as many as LDS allows),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */

@@ -762,7 +762,7 @@ struct pt_ctx {
     int ldsBudget = 20 * 1024;
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
     int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
-    int noneMin = 16;               // lanes waiting for their next object / retirement that make that phase worth a trip
+    int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
     bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 4; int innerKeepEighths = 6;
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
