@@ -20,15 +20,20 @@ pt = ptimport.load()
 import oracle  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = {"C1": (48, 48, 2, {}), "C2": (48, 27, 2, {}), "C3": (48, 27, 3, {}), "C5": (48, 27, 2, dict(subdiv=2))}
+CASES = {"C1": (48, 48, 2, {}), "C2": (48, 27, 2, {}), "C3": (48, 27, 3, {}), "C5": (48, 27, 2, dict(subdiv=2)),
+         "T1": (48, 27, 2, {}),                       # material texture maps: the texture table travels as tex<i>
+         "C5direct": (48, 27, 2, dict(subdiv=2))}     # RAYTRACING = 0 (directDiffuse, N2) on the subsurface / clearcoat scene
 
 
 def main():
     for name, (W, H, frames, kw) in CASES.items():
-        wl = pt.scenes.build(name, W, H, **kw)
+        wl = pt.scenes.build(name.replace("direct", ""), W, H, **kw)
+        if name.endswith("direct"):
+            wl = wl.with_params(RAYTRACING=0)
         seeds = [pt.scenes.frame_seed(f) for f in range(1, frames + 1)]
         frame, cnt = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, frames, seeds, nthreads=4)
         out = {f"b{k}": v for k, v in wl.buffers.items()}
+        out.update({f"tex{i}": a for i, a in wl.textures.items()})
         np.savez_compressed(os.path.join(HERE, f"{name}_{W}x{H}_{frames}f.npz"), frame=frame, counters=cnt, seeds=np.array(seeds, np.int32), sky=wl.sky, **out)
         print(name, W, H, frames, dict(zip(oracle.COUNTERS, cnt.tolist())))
     # RNG known-answer vectors (frag.glsl:686-694) and math-contract samples

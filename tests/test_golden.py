@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(glob.glob(os.path.join(HERE, "C*.npz")))
+CASES = sorted(glob.glob(os.path.join(HERE, "[CT]*.npz")))
 
 
 def _load(path):
@@ -15,7 +15,8 @@ def _load(path):
     name = os.path.basename(path).split("_")[0]
     W, H = [int(v) for v in os.path.basename(path).split("_")[1].split("x")]
     bufs = {int(k[1:]): z[k] for k in z.files if k.startswith("b")}
-    return name, W, H, z, bufs
+    tex = {int(k[3:]): z[k] for k in z.files if k.startswith("tex")}
+    return name, W, H, z, bufs, tex
 
 
 def _same(a, b):
@@ -35,23 +36,28 @@ def test_contract_vectors(oracle):
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
 def test_oracle_and_packers_reproduce_golden(pt, oracle, path):
-    name, W, H, z, bufs = _load(path)
-    kw = dict(subdiv=2) if name == "C5" else {}
-    wl = pt.scenes.build(name, W, H, **kw)
+    name, W, H, z, bufs, tex = _load(path)
+    kw = dict(subdiv=2) if name.startswith("C5") else {}
+    wl = pt.scenes.build(name.replace("direct", ""), W, H, **kw)
+    if name.endswith("direct"):
+        wl = wl.with_params(RAYTRACING=0)
     for k, v in bufs.items():                       # host-side scene producers: same bytes
         assert np.array_equal(wl.buffers[k], v, equal_nan=True), f"binding {k}"
-    frame, cnt = oracle.render_frames(oracle.Scene(bufs, z["sky"]), W, H, 1, len(z["seeds"]), z["seeds"], nthreads=3)
+    assert sorted(wl.textures) == sorted(tex) and all(np.array_equal(wl.textures[i], tex[i]) for i in tex)
+    frame, cnt = oracle.render_frames(oracle.Scene(bufs, z["sky"], tex), W, H, 1, len(z["seeds"]), z["seeds"], nthreads=3)
     assert _same(frame, z["frame"]) and np.array_equal(cnt, z["counters"])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
 def test_hip_reproduces_golden(renderer_mod, path):
-    name, W, H, z, bufs = _load(path)
+    name, W, H, z, bufs, tex = _load(path)
     r = renderer_mod.Renderer(W, H)
     for k, v in bufs.items():
         r.set_buffer(k, v)
     r.set_texture(0, z["sky"])
+    for i, a in tex.items():
+        r.set_texture(i, a)
     r.set_option("count_stats", 1)
     r.reset_frame(); r.reset_counters()
     r.render_batch(1, z["seeds"])
