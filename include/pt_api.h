@@ -79,7 +79,7 @@ int pt_render_batch(pt_ctx* ctx, int first_frame, int n_frames, const int32_t* s
 
 /* ---- overlapped batches (no reference counterpart: the GL driver pipelines the reference's draw calls by itself) ----
  * pt_render_batch_async submits a batch like pt_render_batch, gets the GPU going and returns while jobs are still waiting to
- * be handed to path slots (at most ~22 M of them) and paths are in flight; they finish underneath the next batch, so the
+ * be handed to path slots (at most ~14 M of them) and paths are in flight; they finish underneath the next batch, so the
  * path pool never drains between batches (and, fed frame by frame, grows with the backlog).  Batches overlap as long as the frame inputs (bindings 0, 1, 2, 4) and the scene are unchanged; a change
  * finishes the running work first.  Frames are still added to the FRAME image in u_frameCount order, bit-identical to the
  * synchronous calls.  Every other entry point that reads or modifies results (pt_read_frame, pt_read_display,
@@ -136,7 +136,7 @@ int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_nodes, double* node_bounds, int32_t* node_links,
                  int32_t* node_leaf, int32_t* leaf_tris, int32_t* max_depth);
 
-/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 3/8 of the
+/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 5/8 of the
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,

@@ -754,6 +754,7 @@ struct pt_ctx {
     std::deque<Entry> pending;
     FrameIn streamIn{};             // frame inputs the running stream was started with
     unsigned streamFrames = 0, streamJobs = 0, lastNextJob = 0, lastDelta = 0, launched = 0; int lastCheck = 24, iter = 0; bool draining = false;
+    uint64_t lastSubmitJobs = 0, jobsThisImage = 0, jobsPerImage = 0;      // what the last submission added; jobs submitted for the current / the previous FRAME image
     FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
     Control* hCtl = nullptr;        // pinned copy for the host's polls
     FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr;   // pinned staging (hSeeds: ring like dSeeds)
@@ -1116,9 +1117,8 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + (uint64_t)N;
     const uint64_t maxIters = 2 * ((outstanding + N - 1) / N + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
     uint64_t iters = 0;
-    bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going with one group of iterations
+    bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going: about as many iterations as consume what it added
     while (kick || !satisfied()) {
-        kick = false;
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
         // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
         // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
@@ -1129,7 +1129,9 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             int64_t left = (int64_t)c->streamJobs - (int64_t)c->lastNextJob - (int64_t)c->lastDelta / 2 - (int64_t)arg;
             int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));
             if (left > 0) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, left / perIter));
+            else if (kick) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, (int64_t)c->lastSubmitJobs / perIter));
         }
+        kick = false;
         for (int k = 0; k < CHECK; k++) {
             PoolRun pr; pr.stream = s; pr.st = c->st; pr.launched = c->launched; pr.iter = c->iter;
             const int grid = std::max(1, (int)((pr.launched + BLOCK - 1) / BLOCK));
@@ -1220,8 +1222,8 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         }
         if (c->poolSlots > 0) c->poolActive = c->poolSlots;
         else {                                                    // automatic pool (measured on C3, profiles/): a fifth of the batch when it has to drain at the end
-                                                                  // (short tail), 3/8 of it up to 2^23 when batches overlap (no tail: fewer, fatter launches win)
-            size_t want = std::min<size_t>(std::max<size_t>(async ? nJobs64 * 3 / 8 : nJobs64 / 5, (size_t)1 << 20), (size_t)1 << (async ? 23 : 22));
+                                                                  // (short tail), 5/8 of it up to 2^23 when batches overlap (no tail: fewer, fatter launches win)
+            size_t want = std::min<size_t>(std::max<size_t>(async ? nJobs64 * 5 / 8 : nJobs64 / 5, (size_t)1 << 20), (size_t)1 << (async ? 23 : 22));
             c->poolActive = (int)((std::min<size_t>(want, std::max<size_t>(nJobs64, BLOCK)) + BLOCK - 1) / BLOCK * BLOCK);
         }
         if ((rc = ensurePool(c, (async && c->poolSlots == 0) ? (1 << 23) : 0))) return rc;
@@ -1250,7 +1252,9 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     bool grown = false;
     if (join && async && c->poolSlots == 0) {
         const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + nJobs64;
-        size_t target = std::min<size_t>(std::max<size_t>(outstanding * 3 / 8, (size_t)1 << 20), (size_t)1 << 23);
+        size_t target = std::min<size_t>(std::max<size_t>(outstanding * 5 / 8, (size_t)1 << 20), (size_t)1 << 23);
+        // an image is cheapest to finish two images later (pt_finish_image): keep an image's jobs worth several pool turnovers
+        if (c->jobsPerImage) target = std::min<size_t>(target, std::max<size_t>((size_t)(c->jobsPerImage * 5 / 8), (size_t)1 << 20));
         target = std::min<size_t>((target + BLOCK - 1) / BLOCK * BLOCK, (size_t)c->allocSlots);
         if (target > (size_t)c->poolActive + (size_t)c->poolActive / 4) {
             HIP_TRY(hipMemsetAsync(c->st.G1 + c->poolActive, 0, (target - (size_t)c->poolActive) * 16, s));      // the new slots are dead
@@ -1272,12 +1276,13 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<true>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
     else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<false>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
     c->streamFrames += (unsigned)nFrames; c->streamJobs += (unsigned)nJobs64;
+    c->lastSubmitJobs = nJobs64; c->jobsThisImage += nJobs64;
     pt_ctx::Entry e; e.jobEnd = c->streamJobs; e.f0 = f0; e.nFrames = nFrames; e.firstFrame = firstFrame; e.image = c->curImage;
     c->pending.push_back(e);
     c->draining = false; c->launched = (unsigned)N;              // (if the pool had run dry, k_submit dropped the tail queue)
     HIP_TRY(hipGetLastError());
-    // asynchronous: come back while the backlog of jobs not yet handed out is below what keeps the largest pool fed (2^23 * 8/3)
-    if (async) return pump(c, PUMP_ISSUED, c->poolSlots == 0 ? 22000000 : 0);
+    // asynchronous: come back while the backlog of jobs not yet handed out is below what keeps the largest pool fed (2^23 * 8/5)
+    if (async) return pump(c, PUMP_ISSUED, c->poolSlots == 0 ? 14000000 : 0);
     return pump(c, PUMP_IDLE, 0);
 }
 
@@ -1421,6 +1426,8 @@ int pt_next_image(pt_ctx* c) {
     int rc;
     if ((rc = pump(c, PUMP_IMAGE, next))) return rc;              // nothing may still be on its way into the image taken over
     c->curImage = next;
+    if (c->jobsThisImage) c->jobsPerImage = c->jobsThisImage;
+    c->jobsThisImage = 0;
     HIP_TRY(hipMemsetAsync(c->dImage[next], 0, (size_t)c->nSlotsImg * 16, c->stream));
     return PT_OK;
 }
