@@ -5,17 +5,21 @@
 //
 //   k_frame_setup   uniform work hoisted out of the per-pixel loop: rotationMatrix(ROTATION)
 //                   (:271-283) and the auto-focus ray (:901-906, identical for every pixel)
-//   k_generate      fills the path pool: job -> pixel, rngState = index + u_seed (:896), first
-//                   camera ray (:899-908), trace() prologue (:811-818)
-//   k_extend        rayScene (:548-653): per-object BVH traversal + ellipsoids, LDS-staged top of
-//                   the BVH, per-lane traversal stack in LDS        [the hot kernel]
+//   k_revive        starts jobs in dead path slots: job -> pixel, rngState = index + u_seed (:896), first camera ray
+//                   (:899-908), trace() prologue (:811-818); slot i takes job i when a frame stream starts
+//   k_extend_persist  rayScene (:548-653): per-object BVH traversal + ellipsoids; persistent blocks, LDS-staged top of
+//                   the BVH, in-wave ray refill, one instruction stream per trip chosen by vote   [the hot kernel]
+//                   (k_extend: the simple one-block-per-256-rays form, kept as the cross-check)
 //   k_shade         trace() loop body (:823-879): material, index stack, chooseRay, absorption,
 //                   emission, cut-off, throughput; sky on miss; sample end -> regenerate the next
 //                   sample of the pixel-frame in place (serial rngState) or pull a
-//                   new job with one wave-aggregated atomic; finished pixel-frames go to `colbuf`
-//   k_compact       wave64 ballot/prefix-sum stream compaction of the live path slots (tail)
-//   k_accumulate    FRAME accumulation (:924-933) in u_frameCount order -> bit-identical to
+//                   new job with one block-aggregated atomic; finished pixel-frames go to `colbuf`;
+//                   once job supply runs dry it packs the surviving slots into the next iteration's queue
+//   k_scan_inflight is a live slot still on a frame of the oldest unaccumulated batch? (one pass per host poll)
+//   k_accumulate    FRAME accumulation (:924-933) of one batch in u_frameCount order -> bit-identical to
 //                   frame-at-a-time rendering
+// and a host-side frame-stream scheduler (submitBatch / pump / retireFront below): consecutive batches share one running
+// path pool; the host launches iterations in groups and polls the device's scheduler words (Control).
 //
 // Path state is structure-of-arrays in float4 groups (16 B per lane per access = 1 KiB per wave
 // instruction, fully coalesced).  No MFMA: the path is divergent scalar fp32 + pointer chasing.
