@@ -451,16 +451,15 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
 }
 
 // trace() loop body + sample/job bookkeeping for every live path slot.
-// The kernel is VALU-issue bound and its three big instruction streams are taken by different lanes (hit shading
-// ~75 %, sky ~25 %, new camera ray ~25-30 %), so the block first SORTS its 256 slots by outcome through LDS
-// (wave64 ballot + prefix popcount per wave, 4-wave scan): hits first, misses next, dead slots last.  Waves then
-// run one stream each.  Camera rays (6 Gaussian draws + transforms, the heaviest piece) are not computed by the lane
-// that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes all parked
-// rays densely after a barrier.
+// Thread t of a block handles queue position (or slot) blockIdx*256 + t: every access to the path state is 16 B per lane at
+// consecutive addresses.  (An earlier form sorted the block's slots by outcome — hit / miss / dead — through LDS so that waves
+// ran one instruction stream each; once the kernel had become memory-bound the permuted accesses cost more than the
+// divergence saved: 2-4 % per step on C2-C5, profiles/.)  Camera rays (6 Gaussian draws + transforms, the heaviest piece) are
+// not computed by the lane that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes
+// all parked rays densely after a barrier.
 template <bool TRANS, bool STATS, bool DIRECT, bool TEX>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
                                                  int nSlots, Control* ctl) {
-    __shared__ unsigned sPerm[SHADE_BLOCK], sFlags[SHADE_BLOCK];
     __shared__ uint4 sRegen[SHADE_BLOCK];
     __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase, sRegenCount;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -472,32 +471,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     const unsigned jobEnd = ctl->jobEnd;
     if (writeQueue && blockIdx.x == 0 && threadIdx.x == 0) ctl->exhausted[(iter + 1) & 3] = 1u;     // sticky, also through an empty launch
     if (blockIdx.x * SHADE_BLOCK >= n) return;                           // the grid is sized by the host's last known bound
-    // ---- 1. classify own slot, 2. block-level partition
-    {
-        unsigned q = blockIdx.x * SHADE_BLOCK + threadIdx.x;
-        bool valid = q < n;
-        unsigned i = valid ? (queue ? queue[q] : q) : 0;
-        const unsigned fl = valid ? __float_as_uint(st.G1[i].w) : 0u;
-        bool alive = valid && (fl & FL_ALIVE);
-        bool isHit = false;
-        if (alive) { float4 h = st.H[i]; isHit = !(__float_as_int(h.w) == PRIM_NONE || !(h.x < 1e25f)); }
-        bool isMiss = alive && !isHit;
-        unsigned long long mh = __ballot(isHit), mm = __ballot(isMiss);
-        if (lane == 0) { sCntA[wave] = (unsigned)__popcll(mh); sCntB[wave] = (unsigned)__popcll(mm); }
-        if (threadIdx.x == 0) sRegenCount = 0;
-        __syncthreads();
-        unsigned nHit = 0, hBefore = 0, mBefore = 0;
-#pragma unroll
-        for (int w = 0; w < SHADE_BLOCK / 64; w++) { nHit += sCntA[w]; if (w < wave) { hBefore += sCntA[w]; mBefore += sCntB[w]; } }
-        sPerm[threadIdx.x] = 0xffffffffu;
-        __syncthreads();
-        if (isHit) { unsigned k = hBefore + (unsigned)__popcll(mh & ltMask); sPerm[k] = i; sFlags[k] = fl; }
-        if (isMiss) { unsigned k = nHit + mBefore + (unsigned)__popcll(mm & ltMask); sPerm[k] = i; sFlags[k] = fl; }
-        __syncthreads();
+    if (threadIdx.x == 0) sRegenCount = 0;                               // (first used after the barriers of the job pull)
+    // ---- 1. the slot and its state: every load of the segment is issued here, in one batch — the kernel's critical path is
+    // memory round trips, not bytes.  Only the deep part of the index stack and the medium-entry group wait for the flags.
+    const unsigned q = blockIdx.x * SHADE_BLOCK + threadIdx.x;
+    const bool valid = q < n;
+    const unsigned i = valid ? (queue ? queue[q] : q) : 0u;
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, s1 = g0, s2 = g0, g5 = g0;
+    if (valid) {
+        g1 = st.G1[i]; g0 = st.G0[i]; h = st.H[i]; g2 = st.G2[i]; g3 = st.G3[i]; g4 = st.G4[i];
+        if (TRANS) s0 = st.S0[i];
     }
-    // ---- 3. shade the slot this thread was dealt
-    const unsigned i = sPerm[threadIdx.x];
-    const bool live = i != 0xffffffffu;
+    const bool live = valid && (__float_as_uint(g1.w) & FL_ALIVE);
     Path p;
     p.alive = false;
     bool jobDone = false, needStart = false;
@@ -508,13 +493,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     bool touchS1 = false, touchS2 = false, sampleDone = false, newJob = false, isProbe = false;
     float4 g3in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) {
-        // every load of the segment is issued here, in one batch (the flags came through LDS): the kernel's critical path
-        // is memory round trips, not bytes
-        unpackFlags(p, sFlags[threadIdx.x]);
-        float4 g0 = st.G0[i], g1 = st.G1[i], g2 = st.G2[i], g3 = st.G3[i], h = st.H[i], g4 = st.G4[i];
-        float4 s0 = make_float4(0, 0, 0, 0), s1 = s0, s2 = s0, g5 = s0;
+        unpackFlags(p, __float_as_uint(g1.w));
         if (TRANS) {
-            s0 = st.S0[i];
             touchS1 = p.stackSize >= 4; touchS2 = p.stackSize >= 8;
             if (touchS1) s1 = st.S1[i];
             if (touchS2) s2 = st.S2[i];
