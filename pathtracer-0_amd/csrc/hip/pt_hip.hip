@@ -454,14 +454,12 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
 // Thread t of a block handles queue position (or slot) blockIdx*256 + t: every access to the path state is 16 B per lane at
 // consecutive addresses.  (An earlier form sorted the block's slots by outcome — hit / miss / dead — through LDS so that waves
 // ran one instruction stream each; once the kernel had become memory-bound the permuted accesses cost more than the
-// divergence saved: 2-4 % per step on C2-C5, profiles/.)  Camera rays (6 Gaussian draws + transforms, the heaviest piece) are
-// not computed by the lane that finished a sample: it parks {slot, rng, pixel, flags} in an LDS list and the block computes
-// all parked rays densely after a barrier.
+// divergence saved: 2-4 % per step on C2-C5, profiles/; likewise the dense LDS-listed pass that used to compute the camera
+// rays of new samples for the whole block.)
 template <bool TRANS, bool STATS, bool DIRECT, bool TEX>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
                                                  int nSlots, Control* ctl) {
-    __shared__ uint4 sRegen[SHADE_BLOCK];
-    __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase, sRegenCount;
+    __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const FrameConst& fc = *fcp;
@@ -471,7 +469,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     const unsigned jobEnd = ctl->jobEnd;
     if (writeQueue && blockIdx.x == 0 && threadIdx.x == 0) ctl->exhausted[(iter + 1) & 3] = 1u;     // sticky, also through an empty launch
     if (blockIdx.x * SHADE_BLOCK >= n) return;                           // the grid is sized by the host's last known bound
-    if (threadIdx.x == 0) sRegenCount = 0;                               // (first used after the barriers of the job pull)
     // ---- 1. the slot and its state: every load of the segment is issued here, in one batch — the kernel's critical path is
     // memory round trips, not bytes.  Only the deep part of the index stack and the medium-entry group wait for the flags.
     const unsigned q = blockIdx.x * SHADE_BLOCK + threadIdx.x;
@@ -568,20 +565,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             qOut[sBase + off + (unsigned)__popcll(mk & ltMask)] = i;
         }
     }
-    // ---- 5. store; lanes that start a sample do the prologue themselves and park the camera ray for the dense pass
-    if (needStart) tracePrologue(p);
-    unsigned long long ms = __ballot(needStart);
-    unsigned rbase = 0;
-    if (ms) {
-        if (lane == (__ffsll((long long)ms) - 1)) rbase = atomicAdd(&sRegenCount, (unsigned)__popcll(ms));
-        rbase = __shfl(rbase, __ffsll((long long)ms) - 1);
-    }
-    if (needStart) sRegen[rbase + (unsigned)__popcll(ms & ltMask)] = make_uint4(i, p.rng, p.pix, packFlags(p));
+    // ---- 5. a lane that starts a sample computes its camera ray itself (frag.glsl:899-908); every store stays in slot order
+    if (needStart) { tracePrologue(p); cameraRay(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p.rng, p.O, p.D); }
     if (live) {
-        if (!needStart) {                                          // parked slots get O, D, rng, flags from the dense pass below
-            st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
-            st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
-        }
+        st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
+        st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
         st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.pix));
         {   // incoming light changes only at emitters, at the sky and at sample boundaries: most segments leave the group as it was
             const float4 g3out = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
@@ -601,17 +589,6 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         unsigned long long sm = __ballot(nSamp != 0);
         if (lm && lane == (__ffsll((long long)lm) - 1)) atomicAdd(&ctl->cnt[PT_CNT_SEGMENTS], (unsigned long long)__popcll(lm));
         if (sm && lane == (__ffsll((long long)sm) - 1)) atomicAdd(&ctl->cnt[PT_CNT_SAMPLES], (unsigned long long)__popcll(sm));
-    }
-    __syncthreads();
-    // ---- 6. dense camera-ray pass (frag.glsl:899-908): overwrites O, D, rngState of the parked slots
-    const unsigned nRegen = sRegenCount;
-    for (unsigned k = threadIdx.x; k < nRegen; k += SHADE_BLOCK) {
-        uint4 e = sRegen[k];
-        uint32_t rng = e.y;
-        vec3 O, D;
-        cameraRay(fc, b.W, b.H, (int)(e.z & 0xffffu), (int)(e.z >> 16), rng, O, D);
-        st.G0[e.x] = make_float4(O.x, O.y, O.z, D.x);
-        st.G1[e.x] = make_float4(D.y, D.z, __uint_as_float(rng), __uint_as_float(e.w));
     }
 }
 
