@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 constexpr int CUR_NONE = 0x7ffffffe;
 constexpr int CUR_IDLE = 0x7fffffff;
 
-template <bool COUNT, typename StackT, int TPB>
+template <bool COUNT, typename StackT, int TPB, bool PROBES>
 __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
                                                        Control* ctl, int refillMin, int keepEighths, int nObjLds, int noneMin) {
     extern __shared__ float4 smem[];
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                     const unsigned fl = __float_as_uint(g1.w);
                     if (fl & FL_ALIVE) {
                         d = v3(g0.w, g1.x, g1.y);
-                        probe = (fl & FL_PROBE) != 0;                       // directDiffuse's thickness probe: rayBVH called directly (:668)
+                        probe = PROBES && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
                         o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
                         invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         ob = probe ? (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK) : 0;
@@ -991,7 +991,12 @@ struct PoolRun {            // host view of the path pool while a batch runs
 template <bool COUNT, typename StackT, int TPB>
 void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int grid) {
     int nObjLds = std::min(sc.numObj, 8);
-    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
+    if (c->params.size() >= 12 && c->params[9] != 1.0f) {
+        hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB, true>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
+                           c->innerKeepEighths, nObjLds, c->noneMin);
+        return;
+    }
+    hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB, false>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
                        c->innerKeepEighths, nObjLds, c->noneMin);
 }
 void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
