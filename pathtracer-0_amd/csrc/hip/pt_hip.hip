@@ -68,6 +68,10 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
     unsigned qCount[64];    // entries of queue (j&1) at [32*(j&1)]: two words, 128 B apart
     unsigned long long dbg[16];  // developer build (-DPT_PHASE_STATS): trips and active lanes per phase of the intersect kernel
+#ifdef PT_PHASE_STATS
+    unsigned long long waveEnd[8192];   // s_memrealtime (100 MHz) at which each wave of the last intersect launch finished
+    unsigned long long waveStart[8192]; // ... and started
+#endif
 };
 __device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return ctl->exhausted[(iter + 3) & 3] != 0; }
 
@@ -294,6 +298,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     unsigned slot = 0;
     Counters c;
 #ifdef PT_PHASE_STATS
+    const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
     unsigned long long ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // {trips, active lanes} x {refill, next-object/retire, inner, leaf}, outer trips, live lanes at outer trips
 #define PS(k, lanes) do { ps[2 * (k)]++; ps[2 * (k) + 1] += (unsigned long long)(lanes); } while (0)
 #else
@@ -446,6 +451,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     }
 #ifdef PT_PHASE_STATS
     if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd(&ctl->dbg[k], ps[k]);
+    if (lane == 0 && waveId < 8192) { ctl->waveEnd[waveId] = __builtin_amdgcn_s_memrealtime(); ctl->waveStart[waveId] = tStart; }
 #endif
 #undef PS
 }
@@ -1011,8 +1017,12 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     sc.ldsTris = (sc.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)sc.ldsNodes * 64) / 48) : 0;
     size_t lds = (size_t)sc.ldsNodes * 64 + (size_t)sc.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
+    // Blocks per CU of the grid (pt_set_option 8; 0 = as many as the LDS formula says fit at once).  The default, 4, is one more than is
+    // resident at once on C3-like scenes (≈40 KB of LDS per block: the hardware holds 3): the 4th block of a CU starts when the
+    // first of the three finishes and runs underneath the tails of the other two — measured per-wave start times, scripts/wave_ends.py.
+    // 3 (all resident), 5, 6, 8, 12 and 16 blocks per CU are all slower (profiles/).
     int perCU = std::max(1, std::min((int)(160 * 1024 / std::max<size_t>(lds, 1)), 2048 / tpb));
-    if (c->extendMaxBlocksPerCU > 0) perCU = std::min(perCU, c->extendMaxBlocksPerCU);
+    if (c->extendMaxBlocksPerCU > 0) perCU = c->extendMaxBlocksPerCU;
     int grid = c->numCUs * perCU;
     int maxUseful = (launched + tpb - 1) / tpb;                  // never more blocks than 1 lane per ray
     grid = std::max(1, std::min(grid, maxUseful));
@@ -1512,7 +1522,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
-        case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
+        case 8: if (value < 0 || value > 64) return fail(PT_ERR_ARG, "blocks per CU must be in [0,64]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");
@@ -1547,11 +1557,14 @@ int pt_reset_counters(pt_ctx* c) {
 int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_debug_phase_stats: null argument");
     HIP_TRY(hipSetDevice(c->device));
-    { int rc; if ((rc = flushStream(c))) return rc; }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                     // what the launches so far left; submitted batches are NOT completed first
     Control h;
     HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < n && k < 16; k++) out[k] = h.dbg[k];
+#ifdef PT_PHASE_STATS
+    for (int k = 16; k < n && k < 16 + 8192; k++) out[k] = h.waveEnd[k - 16];
+    for (int k = 16 + 8192; k < n && k < 16 + 2 * 8192; k++) out[k] = h.waveStart[k - 16 - 8192];
+#endif
     return PT_OK;
 }
 

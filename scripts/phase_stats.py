@@ -25,7 +25,7 @@ for kv in sys.argv[4:]:
     k, v = kv.split("="); r.set_option(k, int(v)); print("option", k, v)
 r.reset_counters()
 r.render_batch(1, [scenes.frame_seed(f) for f in range(1, frames + 1)])
-cnt = r.counters()
+cnt = r.counters()            # (completes the batch)
 out = np.zeros(16, np.uint64)
 L = renderer.lib(); L.pt_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 L.pt_debug_phase_stats(r._h, out.ctypes.data, 16)
