@@ -140,8 +140,7 @@ int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_node
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
- * 8 = blocks per CU in the persistent grid (default 4: one more than is resident at once on typical scenes, it runs underneath the
- *     tails of the others; 0 = as many as fit at once),
+ * 8 = blocks per CU in the persistent grid (default 4 = 8 waves per SIMD, all resident; more queue behind them; 0 = as many as fit),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 
@@ -157,7 +156,7 @@ int pt_reset_counters(pt_ctx* ctx);
  * Synchronises.  launches = number of launches, total_ms = summed duration. */
 int pt_kernel_time(pt_ctx* ctx, int kernel, int64_t* launches, double* total_ms);
 int pt_set_timing(pt_ctx* ctx, int enabled);
-/* Developer builds only (-DPT_PHASE_STATS; zeros otherwise): {trips, active lanes} of the persistent intersect kernel's phases
+/* Developer builds only (-DPT_PHASE_STATS, or -DPT_WAVE_STAMPS for the stamps alone; zeros otherwise): {trips, active lanes} of the persistent intersect kernel's phases
  * refill, next-object/retire, inner-node step, leaf step, and of its outer loop, since the last pt_reset_counters; from out[16] on
  * the 100 MHz finish and start times of the (up to 8192) waves of the last intersect launch.  Does not complete submitted batches. */
 int pt_debug_phase_stats(pt_ctx* ctx, uint64_t* out, int n);

@@ -68,7 +68,7 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
     unsigned qCount[64];    // entries of queue (j&1) at [32*(j&1)]: two words, 128 B apart
     unsigned long long dbg[16];  // developer build (-DPT_PHASE_STATS): trips and active lanes per phase of the intersect kernel
-#ifdef PT_PHASE_STATS
+#if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     unsigned long long waveEnd[8192];   // s_memrealtime (100 MHz) at which each wave of the last intersect launch finished
     unsigned long long waveStart[8192]; // ... and started
 #endif
@@ -297,8 +297,10 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     bool probe = false;
     unsigned slot = 0;
     Counters c;
-#ifdef PT_PHASE_STATS
+#if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef PT_PHASE_STATS
     unsigned long long ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // {trips, active lanes} x {refill, next-object/retire, inner, leaf}, outer trips, live lanes at outer trips
 #define PS(k, lanes) do { ps[2 * (k)]++; ps[2 * (k) + 1] += (unsigned long long)(lanes); } while (0)
 #else
@@ -451,6 +453,8 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     }
 #ifdef PT_PHASE_STATS
     if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd(&ctl->dbg[k], ps[k]);
+#endif
+#if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     if (lane == 0 && waveId < 8192) { ctl->waveEnd[waveId] = __builtin_amdgcn_s_memrealtime(); ctl->waveStart[waveId] = tStart; }
 #endif
 #undef PS
@@ -1017,10 +1021,9 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     sc.ldsTris = (sc.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)sc.ldsNodes * 64) / 48) : 0;
     size_t lds = (size_t)sc.ldsNodes * 64 + (size_t)sc.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
-    // Blocks per CU of the grid (pt_set_option 8; 0 = as many as the LDS formula says fit at once).  The default, 4, is one more than is
-    // resident at once on C3-like scenes (≈40 KB of LDS per block: the hardware holds 3): the 4th block of a CU starts when the
-    // first of the three finishes and runs underneath the tails of the other two — measured per-wave start times, scripts/wave_ends.py.
-    // 3 (all resident), 5, 6, 8, 12 and 16 blocks per CU are all slower (profiles/).
+    // Blocks per CU of the grid (pt_set_option 8; 0 = as many as the LDS formula says fit at once).  The default, 4, fills the CU: all
+    // 8192 waves of the grid start within 1 µs of each other (per-wave stamps of a -DPT_WAVE_STAMPS build, scripts/wave_ends.py).
+    // More blocks than fit queue behind the resident ones: 5, 6, 8, 12 and 16 per CU are slower, and so is 3 (6 waves per SIMD).
     int perCU = std::max(1, std::min((int)(160 * 1024 / std::max<size_t>(lds, 1)), 2048 / tpb));
     if (c->extendMaxBlocksPerCU > 0) perCU = c->extendMaxBlocksPerCU;
     int grid = c->numCUs * perCU;
@@ -1561,7 +1564,7 @@ int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
     Control h;
     HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < n && k < 16; k++) out[k] = h.dbg[k];
-#ifdef PT_PHASE_STATS
+#if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     for (int k = 16; k < n && k < 16 + 8192; k++) out[k] = h.waveEnd[k - 16];
     for (int k = 16 + 8192; k < n && k < 16 + 2 * 8192; k++) out[k] = h.waveStart[k - 16 - 8192];
 #endif

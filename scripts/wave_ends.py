@@ -18,6 +18,8 @@ slots = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 23
 wl = scenes.build("C3", W, H)
 r = renderer.Renderer(W, H)
 r.load_workload(wl); r.reset_frame(); r.set_option("path_slots", slots)
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); r.set_option(k, int(v)); print("option", k, v)
 L = renderer.lib(); L.pt_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 out = np.zeros(16 + 2 * 8192, np.uint64)
 r.render_batch_async(1, [scenes.frame_seed(f) for f in range(1, 33)])      # returns with the pool still full: the last launch was a steady-state one
@@ -39,3 +41,10 @@ for x in range(8):                                                   # blocks go
     print(f"   XCD {x}: {len(t)} waves, last-first {float(t.max() - t.min()) / 100:.1f} us;", {p: round(float(t.max() - np.percentile(t, p)) / 100.0, 1) for p in (10, 50, 90, 99)},
           "offset of its last wave vs global last", round(float(allw.max() - t.max()) / 100, 1))
 r.close()
+
+dur = (out[16:16 + 8192].astype(np.int64) - out[16 + 8192:].astype(np.int64)) / 100.0
+w = np.arange(8192)
+print("mean duration (us) by XCD (block % 8):", [round(float(dur[(w // 8) % 8 == x].mean()), 1) for x in range(8)])
+print("mean duration by wave-in-block:", [round(float(dur[w % 8 == k].mean()), 1) for k in range(8)])
+print("mean duration by block index quartile:", [round(float(dur[(w // 8) // 256 == q].mean()), 1) for q in range(4)])
+print("mean duration by slot range decile (wave id):", [round(float(dur[w // 820 == q].mean()), 1) for q in range(10)])
