@@ -56,6 +56,11 @@ class Obj:
         self.nn += 1
         return self.nn
 
+    def vt(self, uv):
+        self.lines.append("vt %.9g %.9g" % tuple(uv))
+        self.nt = getattr(self, "nt", 0) + 1
+        return self.nt
+
     def f(self, a, b, c, na, nb=None, nc=None):
         nb = na if nb is None else nb
         nc = na if nc is None else nc

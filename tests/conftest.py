@@ -45,6 +45,10 @@ def frames_equal(a, b):
 
 def rmse(a, b):
     """per-pixel RMSE over rgb of FRAME.rgb / FRAME.a"""
-    ia = a[..., :3] / np.maximum(a[..., 3:4], 1e-30)
-    ib = b[..., :3] / np.maximum(b[..., 3:4], 1e-30)
-    return float(np.sqrt(np.mean((ia.astype(np.float64) - ib.astype(np.float64)) ** 2)))
+    ia = (a[..., :3] / np.maximum(a[..., 3:4], 1e-30)).astype(np.float64)
+    ib = (b[..., :3] / np.maximum(b[..., 3:4], 1e-30)).astype(np.float64)
+    d = ia - ib
+    both = ~np.isfinite(ia) & ~np.isfinite(ib) & ((ia == ib) | (np.isnan(ia) & np.isnan(ib)))
+    d[both] = 0.0                                  # the reference's own inf/NaN pixels (log(0), 0*inf: SURVEY.md A5), reproduced on both sides
+    d[~np.isfinite(d)] = np.inf                    # ... a NaN on one side only is a difference
+    return float(np.sqrt(np.mean(d ** 2)))

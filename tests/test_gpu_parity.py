@@ -568,3 +568,76 @@ def test_n3_missing_texture_and_mapped_ellipsoid_are_errors(pt, renderer_mod):
         r.render(1, 1)
     assert e.value.code == -5
     r.close()
+
+
+# ---- randomized scenes: every material lobe, texture maps, ellipsoids (stretched, rotated), several objects, odd cameras — in combination
+def _random_workload(pt, seed, W=72, H=44):
+    rs = np.random.RandomState(seed)
+    sc = pt.hostlib.Scene()
+    names = []
+    n_mat = rs.randint(3, 7)
+    textures = {}
+    for m in range(n_mat):
+        name = f"m{m}"; names.append(name)
+        sc.addMaterial(name)
+        sc.setLastMtl("Kd", rs.uniform(0.2, 0.95, 3)); sc.setLastMtl("Ks", rs.uniform(0.2, 1.0, 3))
+        sc.setLastMtl("Pr", float(rs.choice([1.0, rs.uniform(0.0, 1.0)]))); sc.setLastMtl("Pm", float(rs.choice([0.0, 1.0, rs.uniform(0, 1)])))
+        sc.setLastMtl("Pc", float(rs.choice([0.0, rs.uniform(0, 0.8)]))); sc.setLastMtl("Pcr", float(rs.uniform(0, 0.5)))
+        kind = rs.randint(0, 6)
+        if kind == 0:
+            sc.setLastMtl("Ke", rs.uniform(1.0, 12.0, 3))
+        elif kind == 1:
+            sc.setLastMtl("Tr", float(rs.uniform(0.3, 1.0))); sc.setLastMtl("Ni", float(rs.uniform(1.05, 1.9))); sc.setLastMtl("Tf", rs.uniform(0.0, 0.6, 3))
+            sc.setLastMtl("Density", float(rs.uniform(0.2, 3.0)))
+        elif kind == 2:
+            sc.setLastMtl("Tf", rs.uniform(0.1, 0.9, 3)); sc.setLastMtl("Ni", float(rs.uniform(1.1, 1.6)))
+        elif kind == 3:
+            sc.setLastMtl("illum", int(rs.choice([5, 7]))); sc.setLastMtl("Ni", float(rs.uniform(1.1, 2.4)))
+        elif kind == 4:
+            sc.setLastMtl("subsurface", float(rs.uniform(0.2, 0.9))); sc.setLastMtl("subsurfaceColor", rs.uniform(0.1, 1, 3)); sc.setLastMtl("subsurfaceRadius", rs.uniform(0.1, 1, 3))
+            sc.setLastMtl("Ka", rs.uniform(0, 0.2, 3))
+        if m >= 2 and rs.rand() < 0.5:                              # maps on some triangle-only materials (never on the ellipsoids' 0 and 1)
+            for field in rs.choice(["map_Kd", "map_Ks", "map_Ke", "map_Pr", "map_Pm", "map_Pc", "map_Tr", "map_Ka", "map_bump"], size=rs.randint(1, 4), replace=False):
+                t = len(textures) + 1
+                textures[t] = rs.randint(0, 256, size=(rs.randint(1, 9), rs.randint(1, 9), 4)).astype(np.uint8)
+                sc.setLastMtl(str(field), t)
+    o = pt.scenes.Obj()
+    o.group("ground"); o.usemtl(names[0])
+    o.quad_uv((-3, -0.5, -3), (3, -0.5, -3), (3, -0.5, 3), (-3, -0.5, 3), (0, 1, 0), (0.0, 0.0), (2.5, 2.5))
+    for g in range(rs.randint(1, 4)):
+        o.group(f"soup{g}")
+        centre = rs.uniform(-1.0, 1.0, 3) + np.array([0, 0.4, 0.5])
+        for _ in range(rs.randint(8, 120)):
+            o.usemtl(names[rs.randint(0, n_mat)])
+            c = centre + rs.normal(0, 0.45, 3)
+            a, b2, c2 = (c + rs.normal(0, 0.18, 3) for _ in range(3))
+            nrm = np.cross(b2 - a, c2 - a); nrm = nrm / (np.linalg.norm(nrm) + 1e-12)
+            if rs.rand() < 0.5:
+                nrm = nrm + rs.normal(0, 0.2, 3)                    # a "smooth" normal that is not the face normal; components are non-zero -> interpolated branch
+            i0 = o.v(a); i1 = o.v(b2); i2 = o.v(c2); k = o.vn(nrm)
+            if rs.rand() < 0.7:
+                t0 = o.vt(rs.uniform(0.05, 3.0, 2)); t1 = o.vt(rs.uniform(0.05, 3.0, 2)); t2 = o.vt(rs.uniform(0.05, 3.0, 2))
+                o.lines.append(f"f {i0}/{t0}/{k} {i1}/{t1}/{k} {i2}/{t2}/{k}")
+            else:
+                o.lines.append(f"f {i0}//{k} {i1}//{k} {i2}//{k}")
+    sc.addObjectText(o.text(), 0, parentDirectory="")
+    for e in range(rs.randint(0, 4)):
+        rot = rs.uniform(-0.6, 0.6, 3) if rs.rand() < 0.5 else (0.0, 0.0, 0.0)
+        sc.addEllipsoid(rs.uniform(-1.2, 1.2, 3) + np.array([0, 0.3, 0.8]), rs.uniform(0.5, 2.0, 3), rot, float(rs.uniform(0.15, 0.5)), int(rs.randint(0, 2)))
+    cam = (float(rs.uniform(-0.5, 0.5)), float(rs.uniform(0.2, 1.2)), float(rs.uniform(-3.0, -1.8)))
+    rot = (float(rs.uniform(-0.2, 0.3)), float(rs.uniform(-0.25, 0.25)), float(rs.choice([0.0, rs.uniform(-0.3, 0.3)])))
+    sky = rs.randint(0, 256, size=(rs.randint(1, 6), rs.randint(1, 8), 4)).astype(np.uint8)
+    wl = pt.scenes._finish(f"fuzz{seed}", sc, W, H, cam, rot, sky, int(rs.choice([1, 3, 8])), float(rs.choice([1, 4, 8, 12.5])),
+                           blur=float(rs.choice([0.0, 0.001, 0.03])), auto_focus=float(rs.choice([0.0, 1.0])), focal_distance=float(rs.uniform(1.0, 4.0)))
+    wl.textures = textures
+    return wl
+
+
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_scenes(pt, oracle, renderer_mod, seed):
+    wl = _random_workload(pt, seed)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
+    assert_same(got, ref, cnt, ocnt)
+    direct = wl.with_params(RAYTRACING=0)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, direct, 2, extend_mode=seed % 2)
+    assert_same(got, ref, cnt, ocnt)
