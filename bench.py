@@ -98,6 +98,10 @@ def main():
     if args.rehearse_shard:
         unshard.world = 1
 
+    if world > 1:                           # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
+        shard.gather_frame(torch.zeros_like(shard.frame_tensor(r, dev)), unshard, dst=0)
+        torch.cuda.synchronize(dev)
+
     MAX_BATCH = args.max_batch
 
     # One step = one image: reset, spp_step samples per pixel, ONE framebuffer gather.  Consecutive steps overlap on the GPU:
