@@ -152,6 +152,10 @@ def main():
         r.set_option("count_stats", 0)
         r.reset_frame()
 
+    # untimed set-up: one pass sizes and allocates the path pool and the per-frame rings (several GB of hipMalloc), whatever --warmup is
+    step()
+    drain()
+    fence()
     for _ in range(args.warmup):
         step()
     drain()
