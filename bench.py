@@ -4,9 +4,11 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one sample batch of the workload: `frames_per_step` frames x SAMPLE_RES samples/pixel
-over the whole W x H image (tile-sharded over the N ranks), ending with the single gather of the
-accumulated framebuffer on rank 0 (RCCL when N > 1).  Default workload C3 = BASELINE.json
+One step = one image of the workload: `frames_per_step` frames x SAMPLE_RES samples/pixel over the
+whole W x H image (tile-sharded over the N ranks) and the single gather of the accumulated
+framebuffer on rank 0 (RCCL when N > 1).  Consecutive steps overlap on the GPU (a step's last paths
+finish underneath the next step's first ones; its image is gathered two steps later); the K steps,
+their K gathers and the final drain all lie inside the timed region.  --sync: no overlap.  Default workload C3 = BASELINE.json
 configs[2] (1920x1080, 8 bounces, glass + metal spheres: the configuration the metric
 "Msamples/s at 1920x1080x8-bounce" is quoted on; fits one GPU), 32 frames x 8 spp = 256 spp per
 step.  Inputs (scene, path pool, accumulators) are resident in HBM before the timed region.
