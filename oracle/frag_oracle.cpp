@@ -526,6 +526,33 @@ vec3 directDiffuse(Ctx& c, vec3 o, vec3 d) {
     return bgCol(c, d);
 }
 
+// frag.glsl:539-547: the DEBUG traversal heat-map.  rayBVH's .col (:534) per BVH = outputColor*0.1 + (0,0,exp(0.01*(boxTests-200))) +
+// (exp(0.02*(triTests-150)),0,0): outputColor gains (0.1,0,0) per leaf node popped (:478), boxTests 2 per inner node popped (:521) and
+// triTests is never incremented.  Every BVH is traversed on its own from closest_t = 1e30 (a root miss returns 1e30, and 1e30 > 1e30 is
+// false, so even a missed root is popped once), with the un-offset origin and the un-normalised primary direction.
+vec3 debugRayScene(Ctx& c, vec3 o, vec3 d) {
+    const orc_scene* s = c.s;
+    const int numObj = s->obj_indices[0];
+    vec3 ret = v3(0.0f);
+    const bool wasCounting = c.count;
+    uint64_t saved[C_N];
+    for (int k = 0; k < C_N; k++) saved[k] = c.cnt[k];
+    for (int I = 1; I < numObj + 1; I++) {
+        c.count = true; c.cnt[C_BOXTESTS] = 0; c.cnt[C_NODES] = 0;
+        rayBVH(c, o, d, s->obj_indices[I], 1e30f);
+        const int boxTests = (int)c.cnt[C_BOXTESTS] - 1;               // without the root test of :468
+        const int leaves = (int)c.cnt[C_NODES] - boxTests / 2;
+        float ocx = 0.0f;
+        for (int k = 0; k < leaves; k++) ocx = ocx + 0.1f;             // outputColor += vec3(0.1,0,0)
+        const int triTests = 0;
+        vec3 col = v3(ocx * 0.1f + 0.0f + exp_(0.02f * (float)(triTests - 150)), 0.0f * 0.1f + 0.0f + 0.0f, 0.0f * 0.1f + exp_(0.01f * (float)(boxTests - 200)) + 0.0f);
+        ret = ret + v3(col.x / (float)numObj, col.y / (float)numObj, col.z / (float)numObj);
+    }
+    c.count = wasCounting;
+    for (int k = 0; k < C_N; k++) c.cnt[k] = saved[k];
+    return ret;
+}
+
 // frag.glsl:884-934 for one pixel.  texCoord is the pixel centre (vert.glsl:14 interpolated).
 void shadePixel(Ctx& c, int px, int py, int W, int H, int u_frameCount, int u_seed, float mid_to_scene, float* FRAME) {
     float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
@@ -541,6 +568,13 @@ void shadePixel(Ctx& c, int px, int py, int W, int H, int u_frameCount, int u_se
     vec3 col = v3(0.0f);
     uint32_t rng = index + (uint32_t)u_seed;
     Inv g;
+    if (c.DEBUG != 0.0f) {                                            // :916-918
+        col = debugRayScene(c, c.ORIGIN, direction);
+        float* F = FRAME + 4 * ((int64_t)pcy * W + pcx);
+        if ((float)u_frameCount == 1.0f) { F[0] = col.x; F[1] = col.y; F[2] = col.z; F[3] = 1.0f; }
+        else { F[0] = F[0] + col.x; F[1] = F[1] + col.y; F[2] = F[2] + col.z; F[3] = F[3] + 1.0f; }
+        return;
+    }
     for (int rayID = 0; (float)rayID < c.SAMPLE_RES; rayID++) {
         vec3 origin_jittered = c.ORIGIN + vecmat(randLambertianDistVec(c, rng) * c.BLUR, c.camRot);
         float internal_focal_distance = c.FOCAL_DISTANCE;
@@ -572,7 +606,6 @@ int setupCtx(Ctx& c, const orc_scene* s) {
     c.numEllipsoids = (int)s->ellip[0];
     c.camRot = rotationMatrix(c.ROTATION);
     c.count = true;
-    if (c.DEBUG != 0.0f) return -2;                              // DEBUG traversal heat-map: out of scope
     if (c.numImplicits != 0) return -3;                          // implicits are dead code in the reference
     int nm = c.me > 0 ? (int)((s->n_mtl_floats - 1) / c.me) : 0;
     for (int m = 0; m < nm; m++) {                               // every texture a material names must have been uploaded

@@ -620,6 +620,44 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst*
     frame[ls] = F;
 }
 
+// DEBUG != 0 (frag.glsl:916-918): the traversal heat-map of debugRayScene (:539-547) — no random numbers, no samples.  One thread per
+// local pixel; every BVH is traversed on its own from closest_t = 1e30 with the un-offset ORIGIN and the un-normalised primary
+// direction (exactly the thickness probe's rayBVH call), and rayBVH's .col (:534) is rebuilt from the traversal counters:
+// boxTests = 2 per inner node popped, 0.1 per leaf popped, triTests never incremented.  The frames of the batch add the same colour.
+__global__ void __launch_bounds__(64) k_debug_heatmap(DevScene sc, Batch b, const FrameConst* fcp, float4* frame, int firstFrame, int nFrames) {
+    __shared__ int stk[64 * 64];
+    unsigned ls = blockIdx.x * 64 + threadIdx.x;
+    if (ls >= (unsigned)b.nLocal) return;
+    const FrameConst& fc = *fcp;
+    const unsigned xy = b.pixXY[ls];
+    const int px = (int)(xy & 0xffffu), py = (int)(xy >> 16);
+    uint32_t index;
+    if (!pixelIndex(fc, b.W, b.H, px, py, index) || inMouseOverlay(fc, px, py)) return;
+    float tcx = ((float)px + 0.5f) / (float)b.W, tcy = ((float)py + 0.5f) / (float)b.H;
+    vec3 q = v3(((tcx * 2.0f - 1.0f) * -1.0f) * fc.screenSize, ((tcy * 2.0f - 1.0f) * fc.screenHratio) * fc.screenSize, fc.focalLength);
+    const vec3 direction = vecmat(q, fc.camRot);                   // :894, not normalised
+    const vec3 ORIGIN = v3(fc.origin[0], fc.origin[1], fc.origin[2]);
+    vec3 ret = v3(0.0f);
+    for (int ob = 0; ob < sc.numObj; ob++) {
+        Counters c;
+        float t, u, v; int prim;
+        intersectScene<true>(sc, ORIGIN, direction, stk + threadIdx.x, 64, nullptr, nullptr, t, u, v, prim, c, true, ob);
+        const int boxTests = (int)c.boxtests - 1;                  // without the root test of :468
+        const int leaves = (int)c.nodes - boxTests / 2;
+        float ocx = 0.0f;
+        for (int k = 0; k < leaves; k++) ocx = ocx + 0.1f;
+        const float cx = ocx * 0.1f + 0.0f + exp_(0.02f * (float)(0 - 150)), cz = 0.0f * 0.1f + exp_(0.01f * (float)(boxTests - 200)) + 0.0f;
+        ret = ret + v3(cx / (float)sc.numObj, 0.0f / (float)sc.numObj, cz / (float)sc.numObj);
+    }
+    const unsigned slot = (b.shardCount == 1) ? (unsigned)(py * b.W + px) : ls;
+    float4 F = frame[slot];
+    for (int f = 0; f < nFrames; f++) {
+        if ((float)(firstFrame + f) == 1.0f) F = make_float4(ret.x, ret.y, ret.z, 1.0f);
+        else F = make_float4(F.x + ret.x, F.y + ret.y, F.z + ret.z, F.w + 1.0f);
+    }
+    frame[slot] = F;
+}
+
 // Is any live slot still working on a stream frame below fEnd (the oldest batch that has not been accumulated yet)?
 __global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, unsigned fEnd, Control* ctl) {
     unsigned i = blockIdx.x * BLOCK + threadIdx.x;
@@ -1174,7 +1212,23 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     if (c->params.size() < 12) return fail(PT_ERR_ARG, "Parameters (binding 4) not set");
     const float* P = c->params.data();
     const bool direct = P[9] != 1.0f;                            // RAYTRACING == 0: directDiffuse (frag.glsl:655-681, :911-912)
-    if (P[10] != 0.0f) return fail(PT_ERR_UNSUPPORTED, "DEBUG traversal heat-map (frag.glsl:539-547) is out of scope");
+    if (P[10] != 0.0f) {                                          // DEBUG: no paths at all, one small kernel (frag.glsl:916-918)
+        if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
+        if ((rc = flushStream(c))) return rc;
+        if (c->sceneDirty && (rc = buildScene(c))) return rc;
+        if (c->stackDepth > 64) return fail(PT_ERR_SCENE, "DEBUG heat-map: BVH deeper than the 64-entry traversal stack");
+        FrameIn fin;
+        std::memcpy(fin.params, P, 48); std::memcpy(fin.origin, c->origin.data(), 12); std::memcpy(fin.rotation, c->rotation.data(), 12); std::memcpy(fin.mouse, c->mouse.data(), 12);
+        *c->hFrameIn = fin;
+        HIP_TRY(hipMemcpyAsync(c->dFrameIn, c->hFrameIn, sizeof(FrameIn), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, s, c->sc, c->dFrameIn, c->dFc, c->dEllip);
+        std::memset(&c->streamIn, 0xff, sizeof(FrameIn));                          // the frame constants on the device are no stream's any more
+        const Batch b = streamBatch(c);
+        DevScene dsc = c->sc; dsc.ldsNodes = 0; dsc.ldsTris = 0;                    // no LDS tile in this kernel
+        hipLaunchKernelGGL(k_debug_heatmap, dim3((c->nLocal + 63) / 64), dim3(64), 0, s, dsc, b, c->dFc, c->dImage[c->curImage], firstFrame, nFrames);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
     if (!(P[4] >= 1.0f) || P[4] > 255.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,255]");
     if (!(P[5] > 0.0f) || P[5] > 255.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,255]");

@@ -161,11 +161,11 @@ def test_errors_surface(pt, renderer_mod):
     wl = pt.scenes.build("C2", 64, 36)
     r = renderer_mod.Renderer(64, 36)
     r.load_workload(wl)
-    bad = wl.buffers[4].copy(); bad[10] = 1.0                 # DEBUG heat-map: out of scope
+    bad = wl.buffers[4].copy(); bad[2] = 65.0                 # Parameters.resolution that is not the FRAME image's width
     r.set_buffer(4, bad)
     with pytest.raises(renderer_mod.PtError) as e:
         r.render(1, 1)
-    assert e.value.code == -5
+    assert e.value.code == -1
     tri = wl.buffers[3].copy(); tri[36] = 99.0
     r.set_buffer(4, wl.buffers[4]); r.set_buffer(3, tri)
     with pytest.raises(renderer_mod.PtError) as e:
@@ -641,6 +641,21 @@ def test_random_scenes(pt, oracle, renderer_mod, seed):
     direct = wl.with_params(RAYTRACING=0)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, direct, 2, extend_mode=seed % 2)
     assert_same(got, ref, cnt, ocnt)
+
+
+@pytest.mark.parametrize("name,W,H", [("C3", 96, 54), ("C1", 64, 64), ("C4", 64, 36), ("T1", 48, 27)])
+def test_debug_heatmap_mode(pt, oracle, renderer_mod, name, W, H):
+    """DEBUG != 0 (frag.glsl:916-918, debugRayScene :539-547): the traversal heat-map, whole and tile-sharded, in any batch split"""
+    wl = pt.scenes.build(name, W, H).with_params(DEBUG=1)
+    got, ref, _, _ = render_both(pt, oracle, renderer_mod, wl, 3, count_stats=False)
+    assert_same(got, ref)
+    assert got[..., 2].min() > 0 and np.all(got[..., 1] == 0) and np.all(got[..., 3] == 3)
+    acc = np.zeros_like(got)
+    for rank in range(2):
+        rr = renderer_mod.Renderer(W, H, shard_rank=rank, shard_count=2)
+        rr.load_workload(wl); rr.reset_frame(); rr.render(1, 5); rr.render_batch(2, [6, 7])
+        acc += rr.read_frame(); rr.close()
+    assert np.array_equal(acc, ref)
 
 
 def test_mixed_synchronous_and_overlapped_calls(pt, oracle, renderer_mod):

@@ -211,12 +211,27 @@ def test_q6_ellipsoid_from_inside_returns_negative_root(pt, oracle):
     assert code == (3 << 24) and abs(out[0] - 3.0) < 1e-3 and np.allclose(out[4:7], (0, 0, -1), atol=1e-4)
 
 
-def test_oracle_rejects_out_of_scope_modes(pt, oracle):
-    W, H = 8, 6
-    b, sky = _scene(pt, W, H, mats=[{}])
-    b[4][10] = 1.0                             # DEBUG heat-map
-    with pytest.raises(RuntimeError):
-        _render(oracle, b, sky, W, H)
+def test_debug_heatmap_known_answer(pt, oracle):
+    """DEBUG != 0 (frag.glsl:916-918 -> debugRayScene :539-547): one quad = one BVH whose root is an inner node with two leaves.  Every
+    ray pops the root (boxTests = 2 -> blue = exp(0.01*(2-200))); it then pops 0, 1 or 2 leaves (red = 0.1*(0.1 per leaf) + exp(0.02*(0-150)),
+    triTests is never incremented in the shader); green = 0; no random numbers: the seed does not matter and frames just add up."""
+    W, H = 24, 18
+    wl = pt.scenes.build("C2", W, H)          # any workload's camera/params; the scene below replaces its geometry
+    sc = pt.hostlib.Scene(); sc.addMaterial("m")
+    sc.addObjectText("o quad\nvn 0 0 -1\nv -0.5 0.5 1\nv 0.5 0.5 1\nv 0.5 1.5 1\nv -0.5 1.5 1\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n", 0)
+    b = dict(wl.buffers); b.update(sc.pack())
+    b[4] = wl.buffers[4].copy(); b[4][10] = 1.0
+    s = oracle.Scene(b, wl.sky)
+    one, _ = oracle.render(s, W, H, 1, 111, nthreads=2)
+    other, _ = oracle.render(s, W, H, 1, 9999, nthreads=1)
+    assert np.array_equal(one, other)
+    e3, e198 = np.exp(np.float32(-3.0)), np.exp(np.float32(-1.98))
+    assert np.allclose(one[..., 2], e198, rtol=2e-6) and np.all(one[..., 1] == 0) and np.all(one[..., 3] == 1)
+    red = np.unique(np.round((one[..., 0] - e3) * 100).astype(int))
+    assert set(red.tolist()) <= {0, 1, 2} and len(red) >= 2          # some rays miss both leaf boxes, some enter one or both
+    two = one.copy()
+    oracle.render(s, W, H, 2, 5, two, nthreads=2)
+    assert np.array_equal(two[..., :3], one[..., :3] + one[..., :3]) and np.all(two[..., 3] == 2)
 
 
 def test_oracle_threads_and_strides_agree(pt, oracle):
