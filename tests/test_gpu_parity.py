@@ -694,3 +694,28 @@ def test_mixed_synchronous_and_overlapped_calls(pt, oracle, renderer_mod):
     oracle.render_frames(sc, W, H, 2, 1, s[1:2], frame=ref1, nthreads=8)
     assert np.array_equal(c, ref1)
     r.close()
+
+
+def test_gpu_bvh_builder_deep_unbalanced_tree(pt):
+    """triangles on an exponential ladder x = 2^-3i: every split peels a few off, the tree runs into the builder's depth limit of 256
+    (MAX_BVH_BRANCHES, dispatch.java:45) — the level loop, the per-thread subtree builder and the depth cut-off all have to agree with the CPU"""
+    lines = ["o ladder", "vn 0 0 1"]
+    k = 0
+    for i in range(330):
+        x, h = 2.0 ** (-3 * i), 2.0 ** (-3 * i - 3)
+        for (dx, dy) in ((0.0, 0.0), (h, 0.0), (0.0, h)):
+            lines.append("v %.17g %.17g 0" % (x + dx, dy))
+        lines.append("f %d//1 %d//1 %d//1" % (k + 1, k + 2, k + 3))
+        k += 3
+    text = "\n".join(lines) + "\n"
+    out = []
+    for gpu in (False, True):
+        sc = pt.hostlib.Scene(); sc.addMaterial("m")
+        if gpu:
+            sc.use_gpu_bvh_builder(0)
+        sc.addObjectText(text, 0)
+        out.append((sc.pack(), {k2: sc.count(k2) for k2 in ("nodes", "max_depth", "max_leaf", "leaf_indices")}))
+    assert out[0][1] == out[1][1]
+    assert out[0][1]["max_depth"] > 64
+    for b in (3, 10, 11, 12, 13):
+        assert np.array_equal(out[0][0][b].view(np.uint32), out[1][0][b].view(np.uint32)), b
