@@ -29,6 +29,10 @@ import torch.distributed as dist  # noqa: E402
 
 import ptimport  # noqa: E402
 
+try:
+    METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]      # "Msamples/sec (whole node) at 1920x1080x8-bounce; per-pixel RMSE vs ref"
+except Exception:
+    METRIC = "Msamples/sec (whole node) at 1920\u00d71080\u00d78-bounce; per-pixel RMSE vs ref"
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 Q_EXTEND = 44              # algorithmic queue bytes per segment in the intersect kernel: read O,D (24) + write hit record (20), SURVEY.md §8(d)
 
@@ -184,7 +188,7 @@ def main():
     value = samples / dt / 1e6
 
     out = {
-        "metric": "Msamples/s", "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": METRIC, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H}, {cfg['bounces']}-bounce, {spp_step} spp/step ({fps} frames x SAMPLE_RES {sample_res}), "
@@ -246,6 +250,15 @@ def main():
             _, ocnt = oracle.render(sc, W, H, f, scenes.frame_seed(f), buf, nthreads=cores, xs=xs, ys=ys)
             csamp += float(ocnt[4]); nfr += 1
         tcpu = time.perf_counter() - tc
+        # the metric's second half: per-pixel RMSE of the same frames, HIP path vs oracle (the oracle is the checker here, never the product)
+        r.reset_frame()
+        r.render_batch(1, [scenes.frame_seed(f) for f in range(1, nfr + 1)])
+        gpu = r.read_frame()
+        ia, ib = gpu[::ys, ::xs, :3] / float(nfr), buf[::ys, ::xs, :3] / float(nfr)
+        diff = (ia.astype(np.float64) - ib.astype(np.float64))
+        same = bool(np.array_equal(gpu[::ys, ::xs], buf[::ys, ::xs], equal_nan=True))
+        out["parity"] = {"rmse_vs_oracle": float(np.sqrt(np.nanmean(diff ** 2))), "bit_identical": same, "tolerance": 1e-3,
+                         "sample": f"frames 1..{nfr} of the timed workload, every {xs}th pixel in x and y"}
         out["cpu_baseline"] = {"value": round(csamp / tcpu / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                "sample": f"oracle (C++ restatement of frag.glsl), frames 1..{nfr} ({sample_res} spp each) of the same workload at every {xs}th pixel in x and y: "
                                          f"{int(csamp)} samples in {tcpu:.2f} s"}

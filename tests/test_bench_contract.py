@@ -1,0 +1,31 @@
+"""CPU: the bench line committed under profiles/ carries every key of the driver's contract (and bench.py parses its flags without a GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_default_c3.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == base["metric"] and d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["parity"]["bit_identical"] is True and d["parity"]["rmse_vs_oracle"] <= d["parity"]["tolerance"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["value"] > 0
+    assert abs(d["value"] - d["config"]["width"] * d["config"]["height"] * d["config"]["spp_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+
+
+def test_bench_parses_its_flags_without_a_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
