@@ -57,3 +57,49 @@ def test_shard_maps_partition_the_image(pt):
             assert np.all(m[len(v):] == -1)
         assert np.all(seen == 1)
     assert np.array_equal(renderer.shard_map(8, 4, 0, 1), np.arange(32))
+
+
+def _build_c_client(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_client")
+    src = os.path.join(ROOT, "tests", "c", "abi_client.c")
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", exe, src, "-ldl"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_headers_are_valid_c_and_the_c_client_builds(tmp_path):
+    """include/pt_api.h and include/pt_scene.h compile as strict C99 in a plain-C client (what a JNI shim or any compiled host includes)"""
+    _build_c_client(tmp_path)
+
+
+@pytest.mark.gpu
+def test_c_client_renders_what_the_python_wrappers_render(pt, renderer_mod, tmp_path):
+    """the same scene through the C ABIs from plain C (dlopen, no Python in the process) and through hostlib/renderer: same bits"""
+    import subprocess
+    import numpy as np
+    exe = _build_c_client(tmp_path)
+    W, H, frames = 96, 54, 3
+    out = subprocess.run([exe, os.path.join(ROOT, "pathtracer-0_amd"), str(W), str(H), str(frames)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ABI_CLIENT_OK" in out.stdout, out.stdout + out.stderr
+    fnv = out.stdout.split("fnv1a ")[1].split()[0]
+    sc = pt.hostlib.Scene()
+    sc.addMaterial("default"); sc.setLastMtl("Kd", (0.8, 0.8, 0.8)); sc.setLastMtl("Pr", 1)
+    sc.addMaterial("lamp"); sc.setLastMtl("Ke", (12, 12, 12))
+    sc.addMaterial("metal"); sc.setLastMtl("Pm", 1); sc.setLastMtl("Pr", 0.2)
+    quad = ("o floor\nvn 0 1 0\nv -2 0 -2\nv 2 0 -2\nv 2 0 2\nv -2 0 2\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n"
+            "o lamp\nusemtl lamp\nvn 0 -1 0\nv -0.5 2 -0.5\nv 0.5 2 -0.5\nv 0.5 2 0.5\nv -0.5 2 0.5\nf 5//2 7//2 6//2\nf 5//2 8//2 7//2\n")
+    sc.addObjectText(quad, 0, parentDirectory="")
+    sc.addEllipsoid((0.0, 0.5, 0.0), 1.0, 0.0, 0.5, 2)
+    wl = pt.scenes._finish("c_client", sc, W, H, (0.0, 1.0, -3.0), (0.0, 0.0, 0.0), (150, 180, 230), 8, 4)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame()
+    for f in range(1, frames + 1):
+        r.render(f, (1234 + 7919 * f) % 10000)
+    img = r.read_frame(); r.close()
+    h = 1469598103934665603
+    for byte in img.tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert "%016x" % h == fnv
+    assert np.all(img[..., 3] == frames)
