@@ -140,7 +140,7 @@ int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_node
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
- * 8 = blocks per CU in the persistent grid (default 4 = 8 waves per SIMD, all resident; more queue behind them; 0 = as many as fit),
+ * 8 = cap on the blocks per CU of the persistent grid (default 4 = 8 waves per SIMD; never more than fit at once; 0 = no cap),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 

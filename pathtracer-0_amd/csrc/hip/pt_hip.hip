@@ -1059,11 +1059,12 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     sc.ldsTris = (sc.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)sc.ldsNodes * 64) / 48) : 0;
     size_t lds = (size_t)sc.ldsNodes * 64 + (size_t)sc.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
-    // Blocks per CU of the grid (pt_set_option 8; 0 = as many as the LDS formula says fit at once).  The default, 4, fills the CU: all
-    // 8192 waves of the grid start within 1 µs of each other (per-wave stamps of a -DPT_WAVE_STAMPS build, scripts/wave_ends.py).
-    // More blocks than fit queue behind the resident ones: 5, 6, 8, 12 and 16 per CU are slower, and so is 3 (6 waves per SIMD).
+    // Blocks per CU of the grid = what is resident at once (LDS per block; 2048 threads per CU), capped by pt_set_option 8 (default 4).
+    // All waves of the grid start within 1 µs of each other (per-wave stamps of a -DPT_WAVE_STAMPS build, scripts/wave_ends.py).
+    // A grid LARGER than what is resident queues blocks behind the resident ones and is slower (5-16 blocks per CU on C3; C4 and C5,
+    // whose deeper traversal stacks leave room for 3 blocks only, lose 5 % and 13 % with 4).
     int perCU = std::max(1, std::min((int)(160 * 1024 / std::max<size_t>(lds, 1)), 2048 / tpb));
-    if (c->extendMaxBlocksPerCU > 0) perCU = c->extendMaxBlocksPerCU;
+    if (c->extendMaxBlocksPerCU > 0) perCU = std::min(perCU, c->extendMaxBlocksPerCU);
     int grid = c->numCUs * perCU;
     int maxUseful = (launched + tpb - 1) / tpb;                  // never more blocks than 1 lane per ray
     grid = std::max(1, std::min(grid, maxUseful));
@@ -1579,7 +1580,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
-        case 8: if (value < 0 || value > 64) return fail(PT_ERR_ARG, "blocks per CU must be in [0,64]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
+        case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");

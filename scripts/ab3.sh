@@ -2,7 +2,7 @@
 # A/B of prebuilt libraries (build/ab/*.so) on one box over several configs: ab3.sh "C3 C4" lib1.so lib2.so
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 CFGS=$1; shift
-for round in 1 2; do
+for round in ${ROUNDS:-1 2}; do
  for cfg in $CFGS; do
   for lib in "$@"; do
    PT_HIP_LIB=$R/build/ab/$lib timeout -k 10 200 python3 $R/bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --frames-per-step 16 2>/dev/null | python3 -c "
