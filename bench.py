@@ -2,17 +2,20 @@
 """bench.py — Msamples/s of the wavefront path tracer on BASELINE.json's headline workload.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one image of the workload: `frames_per_step` frames x SAMPLE_RES samples/pixel over the
-whole W x H image (tile-sharded over the N ranks) and the single gather of the accumulated
-framebuffer on rank 0 (RCCL when N > 1).  Consecutive steps overlap on the GPU (a step's last paths
-finish underneath the next step's first ones; its image is gathered two steps later); the K steps,
-their K gathers and the final drain all lie inside the timed region.  --sync: no overlap.  Default workload C3 = BASELINE.json
-configs[2] (1920x1080, 8 bounces, glass + metal spheres: the configuration the metric
-"Msamples/s at 1920x1080x8-bounce" is quoted on; fits one GPU), 32 frames x 8 spp = 256 spp per
-step.  Inputs (scene, path pool, accumulators) are resident in HBM before the timed region.
-Prints ONE JSON line on rank 0.
+N > 1 runs in either of two forms, same tile sharding, same single RCCL gather per image:
+  * started plainly (`python bench.py --gpus N`): ONE process, ONE multi-GPU context behind the C ABI (pt_create_multi: a host
+    thread per device inside the library, ncclGather on device 0) — what the reference's single-threaded Java host would call;
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's scaling runs): one process per GPU,
+    torch.distributed "nccl" (= RCCL) gather of the library's packed accumulators, barrier + max-over-ranks timing.
+
+One step = one image of the workload: `frames_per_step` frames x SAMPLE_RES samples/pixel over the whole W x H image (tile-sharded
+over the N GPUs) and the single gather of the accumulated framebuffer on GPU 0.  Consecutive steps overlap on the GPU (a step's
+last paths finish underneath the next step's first ones; its image is gathered two steps later); the K steps, their K gathers and
+the final drain all lie inside the timed region.  --sync: no overlap.  Default workload C3 = BASELINE.json configs[2] (1920x1080,
+8 bounces, glass + metal spheres: the configuration the metric "Msamples/s at 1920x1080x8-bounce" is quoted on; fits one GPU),
+32 frames x 8 spp = 256 spp per step.  Inputs (scene, path pool, accumulators) are resident in HBM before the timed region.
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
@@ -23,21 +26,16 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import ptimport  # noqa: E402
-
 try:
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]      # "Msamples/sec (whole node) at 1920x1080x8-bounce; per-pixel RMSE vs ref"
 except Exception:
-    METRIC = "Msamples/sec (whole node) at 1920\u00d71080\u00d78-bounce; per-pixel RMSE vs ref"
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-Q_EXTEND = 44              # algorithmic queue bytes per segment in the intersect kernel: read O,D (24) + write hit record (20), SURVEY.md §8(d)
+    METRIC = "Msamples/sec (whole node) at 1920×1080×8-bounce; per-pixel RMSE vs ref"
+HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2        # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles each = 1228.8 G/s
+Q_EXTEND = 44                              # algorithmic queue bytes per segment in the intersect kernel: read O,D (24) + write hit record (20), SURVEY.md §8(d)
 
 
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -49,33 +47,100 @@ def main():
     ap.add_argument("--path-slots", type=int, default=None)
     ap.add_argument("--sync", action="store_true", help="drain the path pool at the end of every step (pt_render_batch) instead of overlapping consecutive steps")
     ap.add_argument("--max-batch", type=int, default=32, help="frames per wavefront batch (bounds the per-frame staging buffer: 16 B x pixels x frames)")
-    ap.add_argument("--lds-budget", type=int, default=None)
-    ap.add_argument("--extend-mode", type=int, default=None)
-    ap.add_argument("--extend-tpb", type=int, default=None)
-    ap.add_argument("--extend-cache", type=int, default=None)
-    ap.add_argument("--refill-min", type=int, default=None)
-    ap.add_argument("--none-min", type=int, default=None)
-    ap.add_argument("--extend-blocks-per-cu", type=int, default=None)
-    ap.add_argument("--inner-keep", type=int, default=None)
+    ap.add_argument("--devices", default=None, help="single-process multi-GPU context on these HIP devices, e.g. 0,1,2,3 (default 0..N-1); a device listed "
+                                                    "twice (0,0) rehearses the sharding on one GPU (gather by device copies: RCCL refuses duplicate devices)")
+    ap.add_argument("--dist", action="store_true", help="take the torch.distributed path even at WORLD_SIZE 1 (exercises the RCCL gather of the process-per-GPU form on one GPU)")
+    for name in ("lds-budget", "extend-mode", "extend-tpb", "extend-cache", "refill-min", "none-min", "extend-blocks-per-cu", "inner-keep"):
+        ap.add_argument("--" + name, type=int, default=None)
     ap.add_argument("--rehearse-shard", type=int, nargs=2, metavar=("RANK", "COUNT"), default=None,
                     help="single-process rehearsal of ONE tile shard of a COUNT-GPU run (no collective); reports that shard's rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
-    pt = ptimport.load()
+def roofline_block(args, r, stats, samples, world, dt, value, sample_res):
+    """Per-kernel bounds, each recomputable from tracked files: the per-segment counter figures come from the committed rocprofv3
+    summary profiles/pmc_<config>.json (scripts/pmc_all.sh: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, FETCH_SIZE, WRITE_SIZE ... per
+    segment), the segments per launch and the launch durations are measured live (statistics pass + HIP events on the launch stream)."""
+    n_ext, ms_ext = r.kernel_time("extend")
+    n_sh, ms_sh = r.kernel_time("shade")
+    S = stats["segments"] / max(stats["samples"], 1)
+    seg = S * samples                                   # segments traced in the timed region by all devices (S from the statistics pass)
+    nv, tt, hu = stats["nodes"] / stats["segments"], stats["tritests"] / stats["segments"], stats["hitupd"] / stats["segments"]
+    avg_ext, avg_sh = ms_ext / max(n_ext, 1), ms_sh / max(n_sh, 1)       # mean launch over all devices' launches
+    seg_per_launch = seg / max(n_ext, 1)
+    seg_rate = seg_per_launch / (avg_ext * 1e-3) if avg_ext > 0 else 0.0       # segments/s per device while the intersect kernel runs
+    seg_rate_sh = (seg / max(n_sh, 1)) / (avg_sh * 1e-3) if avg_sh > 0 else 0.0
+    prof, prof_name = None, f"profiles/pmc_{args.config}.json"
+    if os.path.exists(os.path.join(ROOT, prof_name)):
+        prof = json.load(open(os.path.join(ROOT, prof_name)))
+    out = {"kernel": "k_extend_persist", "avg_launch_ms": round(avg_ext, 4), "launches": n_ext, "segments_per_launch": round(seg_per_launch),
+           "median_launch_ms": round(r.kernel_time_median("extend"), 4), "extend_share_of_step": round(ms_ext / max(world, 1) / (dt * 1e3), 3),
+           "segments_per_sample": round(S, 3), "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3)}}
+    ke = (prof or {}).get("kernels", {}).get("k_extend_persist")
+    if ke and "valu_per_segment" in ke:
+        ach = ke["valu_per_segment"] * seg_rate / 1e9
+        out.update({"bound": "valu_issue", "achieved": round(ach, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": round(ach / VALU_PEAK_GINST, 4),
+                    "traffic": round(ke.get("hbm_bytes_per_segment", 0.0) * seg_per_launch) if "hbm_bytes_per_segment" in ke else None,
+                    "valu_insts_per_segment": ke["valu_per_segment"], "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"),
+                    "wait_share": ke.get("wait_share"), "issue_stall_share": ke.get("issue_stall_share"), "counters_from": prof_name,
+                    "note": "the intersect kernel is bound by VALU issue and the latency of dependent node fetches, not by bytes: achieved = SQ_INSTS_VALU per segment "
+                            "(committed rocprofv3 summary) x segments per launch / mean launch time (live HIP events); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per "
+                            "wave64 instruction; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"})
+        if "hbm_bytes_per_segment" in ke:
+            gb = ke["hbm_bytes_per_segment"] * seg_rate / 1e9
+            out["hbm"] = {"achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4),
+                          "bytes_per_segment": ke["hbm_bytes_per_segment"], "note": "measured FETCH_SIZE x2 + WRITE_SIZE per segment (gfx950 correction) x live segment rate"}
+    else:
+        out.update({"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": None, "traffic": None,
+                    "note": f"no committed counter summary {prof_name}: run scripts/pmc_all.sh on a GPU box"})
+    ks = (prof or {}).get("kernels", {}).get("k_shade")
+    sh = {"kernel": "k_shade", "bound": "hbm", "avg_launch_ms": round(avg_sh, 4), "median_launch_ms": round(r.kernel_time_median("shade"), 4),
+          "shade_share_of_step": round(ms_sh / max(world, 1) / (dt * 1e3), 3), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    if ks and "hbm_bytes_per_segment" in ks:
+        gb = ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9
+        sh.update({"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBS, 4), "traffic": round(ks["hbm_bytes_per_segment"] * seg / max(n_sh, 1)),
+                   "bytes_per_segment": ks["hbm_bytes_per_segment"], "lane_util": ks.get("lane_util"), "counters_from": prof_name})
+    out["shade"] = sh
+    # SURVEY.md §8(d)'s algorithmic figure (the reference's buffer layout streamed from memory), kept as a labelled secondary number:
+    # the device-private BVH is served from LDS and L2, so this is NOT a fraction of any roof of this kernel
+    b_ext = Q_EXTEND + nv * 44 + tt * 36 + hu * 124
+    b_samp = S * 304 + S * (nv * 44 + tt * 36 + hu * 124) + 32.0 / sample_res
+    out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "extend_GBps_if_streamed": round(b_ext * seg_rate / 1e9, 1),
+                          "bytes_per_sample_whole_path": round(b_samp, 1), "whole_path_GBps": round(b_samp * value * 1e6 / 1e9 / world, 1),
+                          "note": "SURVEY.md 8(d): 44 B per node visit, 36 B per triangle test, 124 B per hit update, 304 B of queue state per segment in the reference's "
+                                  "layout; a bookkeeping figure, not a roofline fraction"}
+    return out
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    dist_mode = env_world is not None or args.dist          # one process per GPU under torch.distributed.run
+    world = int(env_world) if env_world is not None else (1 if args.dist else args.gpus)
+    rank = int(os.environ.get("RANK", "0")) if dist_mode else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if dist_mode else 0
+    if dist_mode and env_world is not None and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: torch.distributed.run --nproc-per-node must equal --gpus")
+    multi = (not dist_mode) and (args.gpus > 1 or args.devices is not None) and not args.rehearse_shard
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import ptimport
+    ptimport.load()
     from pathtracer_0_amd import renderer, scenes, shard
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(local_rank)
+    if dist_mode:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if env_world is None:
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        dist.init_process_group("nccl", device_id=dev)
 
     cfg = scenes.CONFIGS[args.config]
     W = args.width or cfg["W"]
@@ -85,36 +150,51 @@ def main():
     spp_step = fps * sample_res
     wl = scenes.build(args.config, W, H)
 
-    shard_rank, shard_count = (rank, world) if not args.rehearse_shard else tuple(args.rehearse_shard)
-    r = renderer.Renderer(W, H, device=local_rank, shard_rank=shard_rank, shard_count=shard_count)
+    if multi:
+        devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        n_gpus = len(set(devices))
+        r = renderer.Renderer(W, H, devices=devices)
+        shards = len(devices)
+    else:
+        shard_rank, shard_count = (rank, world) if not args.rehearse_shard else tuple(args.rehearse_shard)
+        r = renderer.Renderer(W, H, device=local_rank, shard_rank=shard_rank, shard_count=shard_count)
+        n_gpus, shards = world, shard_count
     if args.path_slots:
         r.set_option("path_slots", args.path_slots)
-    if args.lds_budget is not None:
-        r.set_option("lds_budget", args.lds_budget)
-    for name, val in (("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min), ("none_min", args.none_min),
-                      ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep)):
+    for name, val in (("lds_budget", args.lds_budget), ("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache),
+                      ("refill_min", args.refill_min), ("none_min", args.none_min), ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep)):
         if val is not None:
             r.set_option(name, val)
-    stream = torch.cuda.Stream(dev)             # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
-    torch.cuda.set_stream(stream)
-    r.set_stream(stream.cuda_stream)
+    if not multi:
+        stream = torch.cuda.Stream(dev)         # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
+        torch.cuda.set_stream(stream)
+        r.set_stream(stream.cuda_stream)
     r.load_workload(wl)
     r.reset_frame()
-    unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev) if not args.rehearse_shard else (lambda t: t)
-    if args.rehearse_shard:
-        unshard.world = 1
 
-    if world > 1:                           # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
-        shard.gather_frame(torch.zeros_like(shard.frame_tensor(r, dev)), unshard, dst=0)
-        torch.cuda.synchronize(dev)
+    if multi:
+        full_view = lambda ptr: torch.as_tensor(shard._DevArray(ptr, (H, W, 4)), device=torch.device("cuda", devices[0]))      # noqa: E731
+        collect = lambda age: full_view(r.gather_image(age))                                                                     # noqa: E731
+        unshard = None
+        collect(0)                              # untimed: RCCL builds its communicators and rings on the first collective
+        r.synchronize()
+    else:
+        collect = None
+        if args.rehearse_shard:
+            unshard = lambda t: t               # noqa: E731
+            unshard.world = 1
+        else:
+            unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev, renderer=r)
+        if dist_mode:                           # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
+            shard.gather_frame(torch.zeros_like(shard.frame_tensor(r, dev)), unshard, dst=0, force_collective=True)
+            torch.cuda.synchronize(dev)
 
     MAX_BATCH = args.max_batch
-
     # One step = one image: reset, spp_step samples per pixel, ONE framebuffer gather.  Consecutive steps overlap on the GPU:
     # a step's last paths finish underneath the next step's first ones (pt_render_batch_async / pt_next_image), and its
     # image is gathered while the next one renders.  Every step's work and gather lie inside the timed region; the fence
     # completes everything that is still in flight.
-    pipeline = shard.StepPipeline(r, unshard, dev, lag=2)      # an image is gathered two steps after it was submitted
+    pipeline = shard.StepPipeline(r, unshard, dev, lag=2, collect=collect, force_collective=dist_mode)      # an image is gathered two steps after it was submitted
 
     def submit():
         done = 0
@@ -132,7 +212,9 @@ def main():
         if args.sync:
             r.reset_frame()
             submit()
-            return shard.gather_frame(shard.frame_tensor(r, dev), unshard, dst=0)
+            if multi:
+                return collect(0)
+            return shard.gather_frame(shard.frame_tensor(r, dev), unshard, dst=0, force_collective=dist_mode)
         return pipeline.step(submit)
 
     def drain():
@@ -141,7 +223,7 @@ def main():
 
     def fence():
         r.synchronize()
-        if world > 1:
+        if dist_mode:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -150,11 +232,14 @@ def main():
     if not args.no_roofline:
         r.set_option("count_stats", 1)
         r.reset_counters()
-        first = 1
         nstat = min(fps, 2)
-        r.render_batch(first, [scenes.frame_seed(f) for f in range(first, first + nstat)])
+        r.render_batch(1, [scenes.frame_seed(f) for f in range(1, 1 + nstat)])
         r.synchronize()
         stats = r.counters()
+        if dist_mode and world > 1:             # whole-image totals
+            t = torch.tensor([float(stats[k]) for k in renderer.COUNTERS], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            stats = dict(zip(renderer.COUNTERS, [int(x) for x in t.tolist()]))
         r.set_option("count_stats", 0)
         r.reset_frame()
 
@@ -177,7 +262,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     r.set_timing(False)
-    if world > 1:
+    if dist_mode:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -187,52 +272,48 @@ def main():
         samples = float((renderer.shard_map(W, H, shard_rank, shard_count) >= 0).sum()) * spp_step * args.steps
     value = samples / dt / 1e6
 
+    if multi:
+        how = f"ONE process, pt_create_multi on devices {devices}: {'RCCL ncclGather' if n_gpus == shards else 'device-copy gather (devices repeat: rehearsal)'} on device {devices[0]}"
+    elif dist_mode:
+        how = f"one process per GPU (torch.distributed nccl = RCCL), dist.gather on rank 0, world {world}"
+    else:
+        how = "one GPU, no collective"
     out = {
-        "metric": METRIC, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": METRIC, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H}, {cfg['bounces']}-bounce, {spp_step} spp/step ({fps} frames x SAMPLE_RES {sample_res}), "
-                               f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs, tile-sharded over {world} GPU(s), 1 framebuffer gather per step",
-                   "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"]},
+                               f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs, tile-sharded over {shards} shard(s) on {n_gpus} GPU(s), 1 framebuffer gather per step",
+                   "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"], "multi_gpu": how},
     }
-
     if args.rehearse_shard:
         out["rehearsal"] = f"shard {shard_rank} of {shard_count} alone on one GPU: value is THIS shard's rate, not a multi-GPU measurement"
+    if multi and n_gpus != shards:
+        out["rehearsal"] = f"{shards} shards on {n_gpus} GPU(s): exercises the multi-GPU context's bookkeeping, not a scaling measurement"
     if stats is not None:
-        n_ext, ms_ext = r.kernel_time("extend")
-        n_sh, ms_sh = r.kernel_time("shade")
-        S = stats["segments"] / max(stats["samples"], 1)
-        seg = S * samples / world                       # segments this rank traced in the timed region (S from the statistics pass)
-        nv, tt, hu = stats["nodes"] / stats["segments"], stats["tritests"] / stats["segments"], stats["hitupd"] / stats["segments"]
-        bytes_per_seg_extend = Q_EXTEND + nv * 44 + tt * 36 + hu * 124
-        bytes_per_sample = S * 304 + S * (nv * 44 + tt * 36 + hu * 124) + 32.0 / sample_res
-        avg_ms = ms_ext / max(n_ext, 1)
-        bytes_per_launch = bytes_per_seg_extend * seg / max(n_ext, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")        # PMC-measured HBM bytes per segment (scripts/profile.sh -> summarize_prof.py)
-        if os.path.exists(tf):
-            tj = json.load(open(tf))
-            k = tj["kernels"].get("k_extend_persist") or tj["kernels"].get("k_extend")
-            if k:
-                traffic = round(k["hbm_bytes_per_segment"] * seg / max(n_ext, 1))
-                traffic_src = "profiles/hbm_traffic.json"
-        out["roofline"] = {"bound": "hbm", "kernel": "k_extend_persist", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                           "avg_launch_ms": round(avg_ms, 4), "launches": n_ext, "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                           "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3), "bytes": round(bytes_per_seg_extend, 1)},
-                           "segments_per_sample": round(S, 3), "bytes_per_sample_whole_path": round(bytes_per_sample, 1),
-                           "whole_path_GBps": round(bytes_per_sample * value * 1e6 / 1e9 / world, 1),
-                           "median_launch_ms": round(r.kernel_time_median("extend"), 4), "shade_median_launch_ms": round(r.kernel_time_median("shade"), 4),
-                           "shade_avg_launch_ms": round(ms_sh / max(n_sh, 1), 4), "extend_share_of_step": round(ms_ext / (dt * 1e3), 3),
-                           "shade_share_of_step": round(ms_sh / (dt * 1e3), 3),
-                           "measured_hbm_GBps": round(traffic / (avg_ms * 1e-3) / 1e9, 1) if traffic and avg_ms > 0 else None,
-                           "note": "achieved = SURVEY.md 8(d) algorithmic bytes (the reference's 44 B per node visit, 36 B per triangle test, 124 B per hit "
-                                   "update, 44 B of ray/hit queue) / launch time; the device-private BVH is served from LDS and L2, so HBM moves only "
-                                   "`traffic` bytes per launch (PMC) and a fraction above 1 means the kernel beats what streaming the reference layout "
-                                   "from HBM would allow; its own limiter is instruction issue and load latency at 8 waves per SIMD (DESIGN.md 2)"}
+        if dist_mode and world > 1:             # launches and device time of all ranks, like the multi-GPU context reports them
+            acc = []
+            for k in ("extend", "shade"):
+                n_k, ms_k = r.kernel_time(k)
+                acc += [float(n_k), ms_k]
+            t = torch.tensor(acc, dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            tot = t.tolist()
+            med = {k: r.kernel_time_median(k) for k in ("extend", "shade")}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            class _All:                         # the same three calls roofline_block makes on a renderer
+                def kernel_time(self, k):
+                    i = 0 if k == "extend" else 2
+                    return int(tot[i]), tot[i + 1]
+
+                def kernel_time_median(self, k):
+                    return med[k]
+            src = _All()
+        else:
+            src = r
+        out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res)
+
+    if rank == 0 and n_gpus == 1 and shards == 1 and not dist_mode and not args.no_cpu_baseline:
         # the reference has no CPU render path: the timed CPU baseline is the oracle ("port")
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
@@ -262,10 +343,23 @@ def main():
         out["cpu_baseline"] = {"value": round(csamp / tcpu / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                "sample": f"oracle (C++ restatement of frag.glsl), frames 1..{nfr} ({sample_res} spp each) of the same workload at every {xs}th pixel in x and y: "
                                          f"{int(csamp)} samples in {tcpu:.2f} s"}
+    elif rank == 0 and (multi or dist_mode) and full is not None and not args.no_cpu_baseline:
+        # N > 1: the gathered image of the last step against a one-GPU render of the same step (K10: bit-identical for every shard count)
+        r1 = renderer.Renderer(W, H, device=(devices[0] if multi else local_rank))
+        r1.load_workload(wl); r1.reset_frame()
+        done = 0
+        while done < fps:
+            n = min(MAX_BATCH, fps - done)
+            r1.render_batch(1 + done, [scenes.frame_seed(f) for f in range(1 + done, 1 + done + n)])
+            done += n
+        ref = r1.read_frame(); r1.close()
+        got = full.cpu().numpy()
+        out["parity"] = {"gathered_image_bit_identical_to_one_gpu_render": bool(np.array_equal(got, ref, equal_nan=True)),
+                         "sample": f"last step's gathered {W}x{H} image ({spp_step} spp) vs the same step rendered unsharded on one GPU"}
     if rank == 0:
         print(json.dumps(out))
     r.close()
-    if world > 1:
+    if dist_mode:
         dist.destroy_process_group()
 
 

@@ -55,6 +55,14 @@ enum {
  * shard_rank / shard_count select the tile shard this context renders (1 GPU: 0 / 1): the image
  * is cut into 32x8-pixel tiles dealt round-robin to the ranks. */
 int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count);
+/* ONE context for several GPUs of the node (SURVEY.md §8(b) "pt_create(backend, n_devices, W, H)", §8(e)): what the reference's
+ * single thread owning the single GL context (dispatch.java:168, :593-713) can drive.  Every entry point below works on it:
+ * uploads replicate the scene on devices[0..n), the render calls render each device's tile shard concurrently (one host thread
+ * per device inside the library), and pt_read_frame / pt_read_display / pt_gather_image perform the ONE collective of an image —
+ * an RCCL gather (ncclGather, single process, ncclCommInitAll) of the packed accumulators on devices[0] — and un-tile it there.
+ * Results are bit-identical to a one-GPU context.  A device listed more than once is a rehearsal of the sharding on fewer GPUs
+ * than shards (RCCL refuses two ranks on one device): the gather then uses device-to-device copies. */
+int pt_create_multi(pt_ctx** out, const int* devices, int n_devices, int width, int height);
 int pt_destroy(pt_ctx* ctx);
 const char* pt_last_error(void);
 
@@ -91,22 +99,28 @@ int pt_next_image(pt_ctx* ctx);
 /* Complete (stream-ordered) every batch submitted for the FRAME image `age` pt_next_image calls ago (0 = current, up to 3).
  * A path lives for up to SAMPLE_RES * MAX_BOUNCES iterations, so an image is cheapest to finish one or two images later. */
 int pt_finish_image(pt_ctx* ctx, int age);
-/* Device pointer of the FRAME image `age` pt_next_image calls ago (0 = current), layout as pt_frame_device. */
+/* Device pointer of the FRAME image `age` pt_next_image calls ago (0 = current), layout as pt_frame_device (one-device contexts). */
 int pt_image_device(pt_ctx* ctx, int age, void** dev_ptr, size_t* n_pixels);
+/* The whole FRAME image `age` pt_next_image calls ago as width*height RGBA32F in device memory (row 0 = bottom): completes that
+ * image like pt_finish_image and, on a multi-GPU context, performs its ONE collective (RCCL gather of the shard accumulators on
+ * devices[0] + un-tiling kernel; stream-ordered there, not synchronised; the buffer is reused by the next gather).  On a
+ * one-device context it is that context's own image. */
+int pt_gather_image(pt_ctx* ctx, int age, void** full_dev);
 
 /* glFinish() (dispatch.java:598) */
 int pt_synchronize(pt_ctx* ctx);
 
 /* glReadPixels-like read-back of the FRAME image as width*height RGBA32F, row 0 = bottom
- * (rgb = running sum, a = frame count; frag.glsl:924-933).  Synchronises.  With shard_count > 1
- * only this shard's pixels are written (others left untouched): the gather across GPUs is the
- * host layer's single RCCL collective on pt_frame_device(). */
+ * (rgb = running sum, a = frame count; frag.glsl:924-933).  Synchronises.  A multi-GPU context
+ * (pt_create_multi) gathers the shards first (one RCCL gather on devices[0]).  A context that is one
+ * shard of a process-per-GPU run (pt_create with shard_count > 1) writes only its own pixels: the
+ * gather is then the host layer's single RCCL collective on pt_frame_device(). */
 int pt_read_frame(pt_ctx* ctx, float* rgba_out);
 
 /* The reference's screenshot path: display colour = FRAME.rgb / frame_count (frag.glsl:932) through an
  * UNORM8 framebuffer (clamp, *255, round to nearest), glReadPixels(GL_RGB, GL_UNSIGNED_BYTE) (dispatch.java:813), the
  * signed-byte packing of :819-822 when java_bytes != 0 (a channel >= 128 borrows 1 from the channel above it), vertical flip
- * (:828-833).  rgb_out: width*height*3 bytes, top row first.  shard_count must be 1.  Synchronises. */
+ * (:828-833).  rgb_out: width*height*3 bytes, top row first.  Needs the whole image: a one-GPU or a multi-GPU context.  Synchronises. */
 int pt_read_display(pt_ctx* ctx, int frame_count, int java_bytes, uint8_t* rgb_out);
 
 /* Device-resident accumulator of this shard: n_pixels RGBA32F in shard-local pixel order
@@ -136,14 +150,6 @@ int pt_set_stream(pt_ctx* ctx, void* hip_stream);
 int pt_build_bvh(int device, const double* tri9, int64_t n_tris, int32_t* n_nodes, double* node_bounds, int32_t* node_links,
                  int32_t* node_leaf, int32_t* leaf_tris, int32_t* max_depth);
 
-/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 5/8 of the
- * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
- * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
- * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
- * 8 = cap on the blocks per CU of the persistent grid (default 4 = 8 waves per SIMD; never more than fit at once; 0 = no cap),
- * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
-int pt_set_option(pt_ctx* ctx, int option, int64_t value);
-
 /* Statistics since the last pt_reset_counters (PT_CNT_* order).  Node/triangle/hit-update counts
  * are only collected when option 1 is set (they slow the intersect kernel down). */
 enum { PT_CNT_SEGMENTS = 0, PT_CNT_NODES, PT_CNT_TRITESTS, PT_CNT_HITUPD, PT_CNT_SAMPLES, PT_CNT_BOXTESTS,
@@ -151,23 +157,7 @@ enum { PT_CNT_SEGMENTS = 0, PT_CNT_NODES, PT_CNT_TRITESTS, PT_CNT_HITUPD, PT_CNT
 int pt_get_counters(pt_ctx* ctx, uint64_t* out, int n);
 int pt_reset_counters(pt_ctx* ctx);
 
-/* Per-kernel device time since pt_set_timing(1) / pt_reset_counters, measured with HIP events on the
- * launch stream: kernel 0 = intersect (extend), 1 = shade, 2 = pool start (revive), 3 = accumulate.
- * Synchronises.  launches = number of launches, total_ms = summed duration. */
-int pt_kernel_time(pt_ctx* ctx, int kernel, int64_t* launches, double* total_ms);
-int pt_set_timing(pt_ctx* ctx, int enabled);
-/* Developer builds only (-DPT_PHASE_STATS, or -DPT_WAVE_STAMPS for the stamps alone; zeros otherwise): {trips, active lanes} of the persistent intersect kernel's phases
- * refill, next-object/retire, inner-node step, leaf step, and of its outer loop, since the last pt_reset_counters; from out[16] on
- * the 100 MHz finish and start times of the (up to 8192) waves of the last intersect launch.  Does not complete submitted batches. */
-int pt_debug_phase_stats(pt_ctx* ctx, uint64_t* out, int n);
-/* median launch duration of that kernel (steady-state figure: the mean also averages the short launches of a batch's tail) */
-int pt_kernel_time_median(pt_ctx* ctx, int kernel, double* median_ms);
-
-/* Debug / parity probes (used by tests): evaluates the device numeric contract.
- * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; host pointers, n elements. */
-int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, size_t n);
-/* Single rays through the intersect kernel: o,d are n*3 f32 (host); out is n*4 f32 (t,u,v) + prim as int bits */
-int pt_debug_intersect(pt_ctx* ctx, const float* o, const float* d, float* out, size_t n);
+/* Tuning knobs, per-kernel timers and the parity probes of the tests are not part of the boundary: include/pt_debug.h. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,42 @@
+/* include/pt_debug.h — developer surface of libpt_hip.so: tuning knobs, per-kernel timers, parity probes.
+ *
+ * Nothing here replaces a reference interface: the boundary a maintainer binds is include/pt_api.h.  These entry points exist for
+ * bench.py (roofline timing), scripts/ (A/B runs) and tests/ (numeric-contract probes).
+ */
+#ifndef PT_DEBUG_H
+#define PT_DEBUG_H
+#include "pt_api.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 5/8 of the
+ * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
+ * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
+ * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
+ * 8 = cap on the blocks per CU of the persistent grid (default 4 = 8 waves per SIMD; never more than fit at once; 0 = no cap),
+ * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
+int pt_set_option(pt_ctx* ctx, int option, int64_t value);
+
+/* Per-kernel device time since pt_set_timing(1) / pt_reset_counters, measured with HIP events on the
+ * launch stream: kernel 0 = intersect (extend), 1 = shade, 2 = pool start (revive), 3 = accumulate.
+ * Synchronises.  launches = number of launches, total_ms = summed duration. */
+int pt_kernel_time(pt_ctx* ctx, int kernel, int64_t* launches, double* total_ms);
+int pt_set_timing(pt_ctx* ctx, int enabled);
+/* Developer builds only (-DPT_PHASE_STATS, or -DPT_WAVE_STAMPS for the stamps alone; zeros otherwise): {trips, active lanes} of the persistent intersect kernel's phases
+ * refill, next-object/retire, inner-node step, leaf step, and of its outer loop, since the last pt_reset_counters; from out[16] on
+ * the 100 MHz finish and start times of the (up to 8192) waves of the last intersect launch.  Does not complete submitted batches. */
+int pt_debug_phase_stats(pt_ctx* ctx, uint64_t* out, int n);
+/* median launch duration of that kernel (steady-state figure: the mean also averages the short launches of a batch's tail) */
+int pt_kernel_time_median(pt_ctx* ctx, int kernel, double* median_ms);
+
+/* Debug / parity probes (used by tests): evaluates the device numeric contract.
+ * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; host pointers, n elements. */
+int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, size_t n);
+/* Single rays through the intersect kernel: o,d are n*3 f32 (host); out is n*4 f32 (t,u,v) + prim as int bits */
+int pt_debug_intersect(pt_ctx* ctx, const float* o, const float* d, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -104,6 +104,52 @@ PM_DEV void rayBox2(vec3 o, vec3 invD, float4 q0, float4 q1, float4 q2, float& L
     }
 }
 
+// rayBox2 on a ray kept as three register pairs: oxy = (o.x, o.y), ozi = (o.z, 1/d.z), ixy = (1/d.x, 1/d.y).  The packed
+// instructions broadcast one half of a pair to both results through op_sel, so no (o.x, o.x) ... duplicates have to be built in
+// registers (the compiler builds them with v_mov pairs at every phase entry).  Same twelve IEEE operations as rayBox2.
+PM_DEV void rayBox2p(f32x2 oxy, f32x2 ozi, f32x2 ixy, float4 q0, float4 q1, float4 q2, float& Ld, float& Rd) {
+    f32x2 a0 = {q0.x, q0.y}, a1 = {q0.z, q0.w}, a2 = {q1.x, q1.y}, a3 = {q1.z, q1.w}, a4 = {q2.x, q2.y}, a5 = {q2.z, q2.w};
+    f32x2 tminx, tminy, tminz, tmaxx, tmaxy, tmaxz;
+#define PK_SUB_LO(d, a, b) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
+#define PK_SUB_HI(d, a, b) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
+#define PK_MUL_LO(d, a, b) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b))
+#define PK_MUL_HI(d, a, b) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b))
+    PK_SUB_LO(tminx, a0, oxy); PK_SUB_HI(tminy, a1, oxy); PK_SUB_LO(tminz, a2, ozi);
+    PK_SUB_LO(tmaxx, a3, oxy); PK_SUB_HI(tmaxy, a4, oxy); PK_SUB_LO(tmaxz, a5, ozi);
+    PK_MUL_LO(tminx, tminx, ixy); PK_MUL_HI(tminy, tminy, ixy); PK_MUL_HI(tminz, tminz, ozi);
+    PK_MUL_LO(tmaxx, tmaxx, ixy); PK_MUL_HI(tmaxy, tmaxy, ixy); PK_MUL_HI(tmaxz, tmaxz, ozi);
+#undef PK_SUB_LO
+#undef PK_SUB_HI
+#undef PK_MUL_LO
+#undef PK_MUL_HI
+    // the slab min/max as written instructions too: the compiler cannot know that an asm result is a canonical float and would
+    // put a canonicalising v_max_f32 x, x, x in front of every minnum/maxnum (v_min_f32 / v_max_f32 ARE minNum / maxNum)
+#define V_MIN(d, a, b) asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define V_MAX(d, a, b) asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define V_MAX3(d, a, b, c) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
+#define V_MIN3(d, a, b, c) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
+    {
+        float t1x, t1y, t1z, t2x, t2y, t2z, tNear, tFar, tN0;
+        V_MIN(t1x, tminx.x, tmaxx.x); V_MIN(t1y, tminy.x, tmaxy.x); V_MIN(t1z, tminz.x, tmaxz.x);
+        V_MAX(t2x, tminx.x, tmaxx.x); V_MAX(t2y, tminy.x, tmaxy.x); V_MAX(t2z, tminz.x, tmaxz.x);
+        V_MAX3(tNear, t1x, t1y, t1z); V_MIN3(tFar, t2x, t2y, t2z);
+        asm("v_max_f32 %0, 0, %1" : "=v"(tN0) : "v"(tNear));                  // tNear > 0 ? tNear : 0 (a NaN tNear gives 0 either way)
+        Ld = (tFar >= tNear && tFar > 0.0f) ? tN0 : 1e30f;
+    }
+    {
+        float t1x, t1y, t1z, t2x, t2y, t2z, tNear, tFar, tN0;
+        V_MIN(t1x, tminx.y, tmaxx.y); V_MIN(t1y, tminy.y, tmaxy.y); V_MIN(t1z, tminz.y, tmaxz.y);
+        V_MAX(t2x, tminx.y, tmaxx.y); V_MAX(t2y, tminy.y, tmaxy.y); V_MAX(t2z, tminz.y, tmaxz.y);
+        V_MAX3(tNear, t1x, t1y, t1z); V_MIN3(tFar, t2x, t2y, t2z);
+        asm("v_max_f32 %0, 0, %1" : "=v"(tN0) : "v"(tNear));
+        Rd = (tFar >= tNear && tFar > 0.0f) ? tN0 : 1e30f;
+    }
+#undef V_MIN
+#undef V_MAX
+#undef V_MAX3
+#undef V_MIN3
+}
+
 // Moeller-Trumbore exactly as rayTri; returns 1e30 in t on a miss
 PM_DEV void rayTri(vec3 o, vec3 d, vec3 v1, vec3 e1, vec3 e2, float& t, float& u, float& v) {
     const float EPSILON = 1e-10f;

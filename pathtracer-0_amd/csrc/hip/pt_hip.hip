@@ -24,6 +24,7 @@
 // Path state is structure-of-arrays in float4 groups (16 B per lane per access = 1 KiB per wave
 // instruction, fully coalesced).  No MFMA: the path is divergent scalar fp32 + pointer chasing.
 #include "../../../include/pt_api.h"
+#include "../../../include/pt_debug.h"
 #include "pt_device.hpp"
 
 #include <algorithm>
@@ -269,8 +270,11 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 constexpr int CUR_NONE = 0x7ffffffe;
 constexpr int CUR_IDLE = 0x7fffffff;
 
+#ifndef PT_EP_WAVES
+#define PT_EP_WAVES 8        // waves per SIMD the register allocation must leave room for (4 blocks of 512 threads per CU)
+#endif
 template <bool COUNT, typename StackT, int TPB, bool PROBES>
-__global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
+__global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
                                                        Control* ctl, int refillMin, int keepEighths, int nObjLds, int noneMin) {
     extern __shared__ float4 smem[];
     float4* ldsN = smem;
@@ -278,20 +282,38 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     // per-lane root-box distances (rayNode(o,d,root) of :468 depends on the ray only, so it is evaluated once per ray
     // when the lane takes the ray — all refilled lanes together — and only compared against `closest` later)
     float* rootDist = reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + threadIdx.x;
+#ifdef PT_V_ROOTS_LDS
+    // the first nObjLds object roots (box + reference, 32 B each) are read by every refill and every next-object step: LDS copies
+    float4* rootsL = reinterpret_cast<float4*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB);
+    StackT* stk = reinterpret_cast<StackT*>(rootsL + 2 * nObjLds) + threadIdx.x;
+    for (int k = threadIdx.x; k < 2 * nObjLds; k += TPB) rootsL[k] = reinterpret_cast<const float4*>(sc.roots)[k];
+#else
     StackT* stk = reinterpret_cast<StackT*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB) + threadIdx.x;
+#endif
     for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += TPB) ldsN[k] = sc.nodes[k];
     for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += TPB) ldsT[k] = sc.tris[k];
     __syncthreads();
     const unsigned* queue = queueIn(ctl, iter) ? qIn : nullptr;
     const unsigned n = queue ? ctl->qCount[32 * (iter & 1)] : (unsigned)nSlots;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->qCount[32 * ((iter + 1) & 1)] = 0;     // cursor of the queue this iteration's shading may write
-    const int lane = threadIdx.x & 63;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    [[maybe_unused]] const int lane = threadIdx.x & 63;
     const unsigned nWaves = gridDim.x * (TPB / 64), waveId = __builtin_amdgcn_readfirstlane(blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));   // scalar: pos/end live in SGPRs
     const unsigned per = (((n + nWaves - 1) / nWaves) + 63u) & ~63u;       // static range of this wave, 64-aligned -> coalesced first fill
     unsigned pos = waveId * per;
     const unsigned end = min(pos + per, n);
+#ifdef PT_V_OPSEL
+    // the ray as three aligned register pairs (rayBox2p): o = (oxy.x, oxy.y, ozi.x), 1/d = (ixy.x, ixy.y, ozi.y)
+    f32x2 oxy = {0.0f, 0.0f}, ozi = {0.0f, 0.0f}, ixy = {0.0f, 0.0f};
+#define RAY_O v3(oxy.x, oxy.y, ozi.x)
+#define RAY_INVD v3(ixy.x, ixy.y, ozi.y)
+#define RAYBOX2(q0, q1, q2, a, b) rayBox2p(oxy, ozi, ixy, q0, q1, q2, a, b)
+    vec3 d = v3(0.0f);
+#else
     vec3 o = v3(0.0f), d = v3(0.0f), invD = v3(0.0f);
+#define RAY_O o
+#define RAY_INVD invD
+#define RAYBOX2(q0, q1, q2, a, b) rayBox2(o, invD, q0, q1, q2, a, b)
+#endif
     float closest = 1e30f, hu = 0.0f, hv = 0.0f;
     int prim = PRIM_NONE, ob = 0, obEnd = 0, sp = 0, cur = CUR_IDLE;
     bool probe = false;
@@ -314,23 +336,41 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
         if (pos < end && nIdle >= refillMin) {                              // wave-uniform
             PS(0, min(nIdle, (int)(end - pos)));
             if (cur == CUR_IDLE) {
-                unsigned q = pos + (unsigned)__popcll(idle & ltMask);
+                // rank of this lane among the idle ones: v_mbcnt (set bits of the mask below the lane), no lane-mask registers
+                unsigned q = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 if (q < end) {
                     slot = queue ? queue[q] : q;
                     float4 g0 = st.G0[slot], g1 = st.G1[slot];
+#ifdef PT_V_REFILL1
+                    // both groups in ONE round trip (left alone the compiler fetches the flags word first and the rest behind the branch)
+                    asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
+#endif
                     const unsigned fl = __float_as_uint(g1.w);
                     if (fl & FL_ALIVE) {
                         d = v3(g0.w, g1.x, g1.y);
                         probe = PROBES && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
+#ifdef PT_V_OPSEL
+                        { const vec3 o_ = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
+                          oxy = f32x2{o_.x, o_.y}; ozi = f32x2{o_.z, 1.0f / d.z}; ixy = f32x2{1.0f / d.x, 1.0f / d.y}; }
+#else
                         o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
                         invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+#endif
                         ob = probe ? (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK) : 0;
                         obEnd = probe ? ob + 1 : sc.numObj;
                         closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; sp = 0; cur = CUR_NONE;
                         for (int k = 0; k < nObjLds; k += 2) {              // two root boxes per packed-f32 test, like the two children of a node
+#ifdef PT_V_ROOTS_LDS
+                            const int kb = min(k + 1, nObjLds - 1);
+                            const float4 a0 = rootsL[2 * k], a1 = rootsL[2 * k + 1], b0 = rootsL[2 * kb], b1 = rootsL[2 * kb + 1];
+                            ObjRoot A, B;
+                            A.bmin[0] = a0.x; A.bmin[1] = a0.y; A.bmin[2] = a0.z; A.bmax[0] = a0.w; A.bmax[1] = a1.x; A.bmax[2] = a1.y;
+                            B.bmin[0] = b0.x; B.bmin[1] = b0.y; B.bmin[2] = b0.z; B.bmax[0] = b0.w; B.bmax[1] = b1.x; B.bmax[2] = b1.y;
+#else
                             const ObjRoot A = sc.roots[k], B = sc.roots[min(k + 1, nObjLds - 1)];
+#endif
                             float da, db;
-                            rayBox2(o, invD, make_float4(A.bmin[0], B.bmin[0], A.bmin[1], B.bmin[1]), make_float4(A.bmin[2], B.bmin[2], A.bmax[0], B.bmax[0]),
+                            RAYBOX2(make_float4(A.bmin[0], B.bmin[0], A.bmin[1], B.bmin[1]), make_float4(A.bmin[2], B.bmin[2], A.bmax[0], B.bmax[0]),
                                     make_float4(A.bmax[1], B.bmax[1], A.bmax[2], B.bmax[2]), da, db);
                             rootDist[k * TPB] = da;
                             if (k + 1 < nObjLds) rootDist[(k + 1) * TPB] = db;
@@ -352,10 +392,15 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
             PS(1, nNone);
             if (cur == CUR_NONE) {
                 while (ob < obEnd) {
-                    float rd;
+                    float rd; int rref;
+#ifdef PT_V_ROOTS_LDS
+                    if (ob < nObjLds) { rd = rootDist[ob * TPB]; rref = __float_as_int(rootsL[2 * ob + 1].z); }
+                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(RAY_O, RAY_INVD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); rref = R.ref; }
+#else
                     if (ob < nObjLds) rd = rootDist[ob * TPB];
-                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); }
-                    const int rref = sc.roots[ob].ref;
+                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(RAY_O, RAY_INVD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); }
+                    rref = sc.roots[ob].ref;
+#endif
                     ob++;
                     if (COUNT) c.boxtests++;
                     if (rd > closest) continue;
@@ -368,8 +413,8 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                         const EllipRec& E = sc.ellip[i];
                         vec3 cc = v3(E.c[0], E.c[1], E.c[2]);
                         float t;
-                        if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
-                        else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        if (E.rotated) t = rayEllipsoid(vecmat(RAY_O, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        else t = rayEllipsoid(RAY_O, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
                         if (t < closest) {
                             if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) hu = __int_as_float(prim);   // see intersectScene
                             closest = t; prim = PRIM_ELLIPSOID | i;
@@ -392,7 +437,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                     loadNode(sc, ldsN, cur, q0, q1, q2, q3);
                     if (COUNT) { c.nodes++; c.boxtests += 2; }
                     float Ld, Rd;
-                    rayBox2(o, invD, q0, q1, q2, Ld, Rd);
+                    RAYBOX2(q0, q1, q2, Ld, Rd);
                     const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                     if (COUNT) { if (Ld < closest && lref == REF_EMPTY) c.nodes++; if (Rd < closest && rref == REF_EMPTY) c.nodes++; }
                     // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
@@ -428,7 +473,7 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
                     unsigned idl = __float_as_uint(t2.y);
                     float t, u, v;
                     if (COUNT) c.tritests++;
-                    rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
+                    rayTri(RAY_O, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
                     if (t > 0.0f && t < closest) {                          // :489
                         closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
                         if (COUNT) c.hitupd++;
@@ -458,6 +503,9 @@ __global__ void __launch_bounds__(TPB) k_extend_persist(DevScene sc, State st, c
     if (lane == 0 && waveId < 8192) { ctl->waveEnd[waveId] = __builtin_amdgcn_s_memrealtime(); ctl->waveStart[waveId] = tStart; }
 #endif
 #undef PS
+#undef RAY_O
+#undef RAY_INVD
+#undef RAYBOX2
 }
 
 // trace() loop body + sample/job bookkeeping for every live path slot.
@@ -731,7 +779,9 @@ __global__ void k_debug_math(int fn, const float* x, const float* y, float* out,
 
 // ------------------------------------------------------------------------------------------------ host side
 
+struct MultiCtx;
 struct pt_ctx {
+    MultiCtx* multi = nullptr;      // != nullptr: a multi-GPU group (pt_create_multi, pt_multi.hpp); everything below then lives in its per-device contexts
     int device = 0, W = 0, H = 0, shardRank = 0, shardCount = 1;
     hipStream_t ownStream = nullptr, stream = nullptr;
     // raw SSBO contents (host copies, glBufferData semantics)
@@ -740,13 +790,14 @@ struct pt_ctx {
     std::vector<uint8_t> sky; int skyW = 0, skyH = 0;
     struct HostTex { std::vector<uint8_t> rgba; int w = 0, h = 0; };
     std::vector<HostTex> textures;          // bindless table beyond the sky (index 0 mirrors `sky`)
-    std::vector<float4*> dTexData; TexRec* dTexTable = nullptr;
+    float4* dTexels = nullptr; TexRec* dTexTable = nullptr;      // all textures beyond the sky in one allocation + the bindless-style table
     bool sceneDirty = true, frameInDirty = true;
     bool trans = false, anySubsurface = false, ambiguousTriObj = false, anyMaps = false; int* dTriObj = nullptr;
     int stackDepth = 1;
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
     float4* dSky = nullptr;
+    unsigned char* dDisplay = nullptr;      // scratch of pt_read_display (W*H*3 bytes, allocated on first use)
     DevScene sc{};
     // shard
     std::vector<int32_t> pixList; int nLocal = 0, nSlotsImg = 0; int* dPixList = nullptr; unsigned* dPixXY = nullptr; int* dAllMaps = nullptr;
@@ -954,21 +1005,21 @@ int buildScene(pt_ctx* c) {
     for (size_t k = 0; k < skyf.size(); k++)
         skyf[k] = f4((float)c->sky[4 * k] / 255.0f, (float)c->sky[4 * k + 1] / 255.0f, (float)c->sky[4 * k + 2] / 255.0f, (float)c->sky[4 * k + 3] / 255.0f);
     if ((rc = uploadVec((void**)&c->dSky, skyf.data(), skyf.size() * 16, s))) return rc;
-    for (float4* p : c->dTexData) if (p) HIP_TRY(hipFree(p));
-    c->dTexData.assign(std::max<size_t>(c->textures.size(), 1), nullptr);
-    std::vector<TexRec> table(c->dTexData.size());
+    // the texture table beyond the sky: ONE allocation and one asynchronous copy for all textures
+    std::vector<TexRec> table(std::max<size_t>(c->textures.size(), 1));
     table[0].data = c->dSky; table[0].w = c->skyW; table[0].h = c->skyH;
+    std::vector<float4> texels; std::vector<size_t> texOff(table.size(), 0);
     for (size_t ti = 1; ti < c->textures.size(); ti++) {
         const pt_ctx::HostTex& T = c->textures[ti];
         table[ti].data = nullptr; table[ti].w = T.w; table[ti].h = T.h;
         if (T.rgba.empty()) continue;
-        std::vector<float4> tf((size_t)T.w * T.h);
-        for (size_t k = 0; k < tf.size(); k++)
-            tf[k] = f4((float)T.rgba[4 * k] / 255.0f, (float)T.rgba[4 * k + 1] / 255.0f, (float)T.rgba[4 * k + 2] / 255.0f, (float)T.rgba[4 * k + 3] / 255.0f);
-        HIP_TRY(hipMalloc((void**)&c->dTexData[ti], tf.size() * 16));
-        HIP_TRY(hipMemcpy(c->dTexData[ti], tf.data(), tf.size() * 16, hipMemcpyHostToDevice));
-        table[ti].data = c->dTexData[ti];
+        texOff[ti] = texels.size();
+        const size_t nTex = (size_t)T.w * T.h;
+        for (size_t k = 0; k < nTex; k++)
+            texels.push_back(f4((float)T.rgba[4 * k] / 255.0f, (float)T.rgba[4 * k + 1] / 255.0f, (float)T.rgba[4 * k + 2] / 255.0f, (float)T.rgba[4 * k + 3] / 255.0f));
     }
+    if ((rc = uploadVec((void**)&c->dTexels, texels.data(), texels.size() * 16, s))) return rc;
+    for (size_t ti = 1; ti < c->textures.size(); ti++) if (!c->textures[ti].rgba.empty()) table[ti].data = c->dTexels + texOff[ti];
     if ((rc = uploadVec((void**)&c->dTexTable, table.data(), table.size() * sizeof(TexRec), s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     DevScene& sc = c->sc;
@@ -1001,6 +1052,7 @@ int ensurePool(pt_ctx* c, int capacity) {               // capacity >= poolActiv
     capacity = std::max(capacity, c->poolActive);
     if (c->allocSlots >= capacity && c->allocTrans == c->trans) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->allocSlots = 0;                                            // until every allocation below has succeeded there is no pool
     float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H};
     for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
     for (unsigned** q : {&c->dQueue[0], &c->dQueue[1]}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
@@ -1039,7 +1091,7 @@ struct PoolRun {            // host view of the path pool while a batch runs
 template <bool COUNT, typename StackT, int TPB>
 void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int grid) {
     int nObjLds = std::min(sc.numObj, 8);
-    if (c->params.size() >= 12 && c->params[9] != 1.0f) {
+    if (c->streamIn.params[9] != 1.0f) {                         // RAYTRACING of the running stream, not of a later upload
         hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB, true>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
                            c->innerKeepEighths, nObjLds, c->noneMin);
         return;
@@ -1052,7 +1104,7 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     DevScene sc = c->sc;
     int tpb = c->extendTpb;
     // LDS per block: [node tile][triangle tile][root-box distances][traversal stacks]; the tile takes what the fixed parts leave
-    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stack16 ? 2 : 4) + 64;
+    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stack16 ? 2 : 4) + 64 + 32 * 8;     // + the LDS copies of up to 8 object roots
     size_t avail = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
     size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, avail);
     {   // a smaller node tile (down to 6 KB) if that lets one more block — two more waves per SIMD — live on the CU: occupancy is worth
@@ -1121,7 +1173,9 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 int pump(pt_ctx* c, PumpUntil until, int arg) {
     if (c->pending.empty()) return 0;
     hipStream_t s = c->stream;
-    const float* P = c->params.data();
+    // the Parameters block the running stream was started with: a later pt_set_buffer(PT_BIND_PARAMS) only takes effect with the
+    // next stream (submitBatch finishes this one first), so the remaining iterations keep their kernel variants and bounds
+    const float* P = c->streamIn.params;
     const bool direct = P[9] != 1.0f;
     const Batch b = streamBatch(c);
     const int N = c->poolActive;
@@ -1176,6 +1230,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             c->iter = (c->iter + 1) & 0x3fffffff;
             iters++;
         }
+        HIP_TRY(hipGetLastError());                                // a failed launch surfaces here, not as "did not drain"
         // has the oldest batch been handed out completely (as of the previous look)?  then see whether it is still in flight
         const bool scan = !c->pending.empty() && c->lastNextJob >= c->pending.front().jobEnd;
         if (scan) {
@@ -1340,32 +1395,27 @@ int resolveTimes(pt_ctx* c) {
 
 }  // namespace
 
+#include "pt_multi.hpp"
+
 // ------------------------------------------------------------------------------------------------ C ABI
 
 int pt_set_error_(int code, const std::string& msg) { return fail(code, msg); }      // for pt_bvh.hip
+
+// a group context hands the call to the host thread of every device context and joins them (pt_multi.hpp)
+#define MULTI_ALL(c, call) do { if ((c) && (c)->multi) return multiRun(*(c)->multi, [=](pt_ctx* k) { return call; }); } while (0)
 
 extern "C" {
 
 const char* pt_last_error(void) { return g_err.c_str(); }
 
-int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count) {
-    if (!out || width < 1 || height < 1 || width > 65535 || height > 65535 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(PT_ERR_ARG, "pt_create: bad argument");
-    int nDev = 0;
-    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= nDev) return fail(PT_ERR_NO_DEVICE, "HIP device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-    pt_ctx* c = new pt_ctx();
-    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    c->device = device; c->W = width; c->H = height; c->shardRank = shard_rank; c->shardCount = shard_count;
+namespace {
+int initContext(pt_ctx* c, int width, int height, int shard_rank, int shard_count) {
     HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
     c->stream = c->ownStream;
     shardPixels(width, height, shard_rank, shard_count, c->pixList);
     c->nLocal = (int)c->pixList.size();
     c->nSlotsImg = shard_count == 1 ? width * height : (int)shardSlots(width, height, shard_count);
-    if (c->nLocal == 0) { delete c; return fail(PT_ERR_ARG, "this shard owns no pixels (more shards than tiles)"); }
+    if (c->nLocal == 0) return fail(PT_ERR_ARG, "this shard owns no pixels (more shards than tiles)");
     HIP_TRY(hipMalloc((void**)&c->dPixList, (size_t)c->nLocal * 4));
     HIP_TRY(hipMemcpy(c->dPixList, c->pixList.data(), (size_t)c->nLocal * 4, hipMemcpyHostToDevice));
     {
@@ -1382,20 +1432,66 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
     HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
     HIP_TRY(hipHostMalloc((void**)&c->hCtl, sizeof(Control), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->hFrameIn, sizeof(FrameIn), hipHostMallocDefault));
+    return 0;
+}
+}  // namespace
+
+int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count) {
+    if (!out || width < 1 || height < 1 || width > 65535 || height > 65535 || shard_count < 1 || shard_rank < 0 || shard_rank >= shard_count) return fail(PT_ERR_ARG, "pt_create: bad argument");
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= nDev) return fail(PT_ERR_NO_DEVICE, "HIP device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) return fail(PT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    pt_ctx* c = new pt_ctx();
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->device = device; c->W = width; c->H = height; c->shardRank = shard_rank; c->shardCount = shard_count;
     c->imp = {0.0f}; c->ellip = {0.0f}; c->objidx = {0};
     c->mouse = {-1.0e6f, -1.0e6f, 0.0f};
+    const int rc = initContext(c, width, height, shard_rank, shard_count);
+    if (rc) { const std::string msg = g_err; pt_destroy(c); return fail(rc, msg); }      // nothing of a half-built context is left behind
     *out = c;
+    return PT_OK;
+}
+
+int pt_create_multi(pt_ctx** out, const int* devices, int n_devices, int width, int height) {
+    if (!out || !devices || n_devices < 1 || n_devices > 64 || width < 1 || height < 1) return fail(PT_ERR_ARG, "pt_create_multi: bad argument");
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    for (int i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= nDev) return fail(PT_ERR_NO_DEVICE, "pt_create_multi: HIP device index out of range");
+    pt_ctx* g = new pt_ctx();
+    g->W = width; g->H = height; g->device = devices[0];
+    MultiCtx* M = new MultiCtx();
+    g->multi = M;
+    M->n = n_devices; M->devices.assign(devices, devices + n_devices);
+    for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++) if (devices[i] == devices[j]) M->sameDevice = true;
+    M->kids.assign(n_devices, nullptr);
+    for (int i = 0; i < n_devices; i++) {
+        M->workers.emplace_back(new Worker());
+        Worker* w = M->workers.back().get();
+        w->th = std::thread([w] { w->loop(); });
+    }
+    for (int i = 0; i < n_devices; i++) {
+        pt_ctx** slot = &M->kids[i]; const int dev = devices[i];
+        M->workers[i]->post([=] { return pt_create(slot, dev, width, height, i, n_devices); });
+    }
+    int rc = 0; std::string err;
+    for (int i = 0; i < n_devices; i++) { int r = M->workers[i]->wait(); if (r && !rc) { rc = r; err = "device " + std::to_string(devices[i]) + ": " + M->workers[i]->err; } }
+    if (rc) { M->kids.erase(std::remove(M->kids.begin(), M->kids.end(), nullptr), M->kids.end()); multiFree(g); delete g; return fail(rc, err); }
+    *out = g;
     return PT_OK;
 }
 
 int pt_destroy(pt_ctx* c) {
     if (!c) return PT_OK;
+    if (c->multi) { multiFree(c); delete c; return PT_OK; }
     hipSetDevice(c->device);
     flushStream(c);
     hipStreamSynchronize(c->stream);
-    for (float4* p : c->dTexData) if (p) hipFree(p);
-    void* ptrs[] = {c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
-                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl};
+    void* ptrs[] = {c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
+                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hCtl) hipHostFree(c->hCtl);
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
@@ -1408,6 +1504,7 @@ int pt_destroy(pt_ctx* c) {
 
 int pt_set_buffer(pt_ctx* c, int binding, const void* data, size_t bytes) {
     if (!c || (!data && bytes)) return fail(PT_ERR_ARG, "pt_set_buffer: null argument");
+    if (c->multi) { for (pt_ctx* k : c->multi->kids) { int rc = pt_set_buffer(k, binding, data, bytes); if (rc) return rc; } return PT_OK; }      // the scene is replicated
     if (bytes % 4) return fail(PT_ERR_ARG, "pt_set_buffer: size must be a multiple of 4 bytes");
     const float* f = static_cast<const float*>(data); const int32_t* i = static_cast<const int32_t*>(data); size_t n = bytes / 4;
     switch (binding) {
@@ -1431,6 +1528,7 @@ int pt_set_buffer(pt_ctx* c, int binding, const void* data, size_t bytes) {
 
 int pt_set_texture(pt_ctx* c, int index, int w, int h, const uint8_t* rgba8) {
     if (!c || !rgba8 || w < 1 || h < 1) return fail(PT_ERR_ARG, "pt_set_texture: bad argument");
+    if (c->multi) { for (pt_ctx* k : c->multi->kids) { int rc = pt_set_texture(k, index, w, h, rgba8); if (rc) return rc; } return PT_OK; }
     if (index < 0 || index > 4095) return fail(PT_ERR_ARG, "texture index out of range [0,4095]");
     if (index == 0) { c->sky.assign(rgba8, rgba8 + (size_t)w * h * 4); c->skyW = w; c->skyH = h; }
     if ((size_t)index >= c->textures.size()) c->textures.resize((size_t)index + 1);
@@ -1441,6 +1539,7 @@ int pt_set_texture(pt_ctx* c, int index, int w, int h, const uint8_t* rgba8) {
 
 int pt_reset_frame(pt_ctx* c) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    MULTI_ALL(c, pt_reset_frame(k));
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = flushStream(c))) return rc;
@@ -1448,18 +1547,26 @@ int pt_reset_frame(pt_ctx* c) {
     return PT_OK;
 }
 
-int pt_render(pt_ctx* c, int frame_count, int seed) { if (!c) return fail(PT_ERR_ARG, "null context"); int32_t s = seed; return submitBatch(c, frame_count, 1, &s, false); }
+int pt_render(pt_ctx* c, int frame_count, int seed) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    MULTI_ALL(c, pt_render(k, frame_count, seed));
+    int32_t s = seed;
+    return submitBatch(c, frame_count, 1, &s, false);
+}
 int pt_render_batch(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
     if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch: null argument");
+    MULTI_ALL(c, pt_render_batch(k, first_frame, n_frames, seeds));
     return submitBatch(c, first_frame, n_frames, seeds, false);
 }
 int pt_render_batch_async(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
     if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch_async: null argument");
+    MULTI_ALL(c, pt_render_batch_async(k, first_frame, n_frames, seeds));
     return submitBatch(c, first_frame, n_frames, seeds, true);
 }
 
 int pt_next_image(pt_ctx* c) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    MULTI_ALL(c, pt_next_image(k));
     HIP_TRY(hipSetDevice(c->device));
     const int next = (c->curImage + 1) % pt_ctx::IMAGES;
     if (!c->dImage[next]) HIP_TRY(hipMalloc((void**)&c->dImage[next], (size_t)c->nSlotsImg * 16));
@@ -1474,12 +1581,14 @@ int pt_next_image(pt_ctx* c) {
 
 int pt_finish_image(pt_ctx* c, int age) {
     if (!c || age < 0 || age >= pt_ctx::IMAGES) return fail(PT_ERR_ARG, "pt_finish_image: age must be in [0,3] (0 = current image)");
+    MULTI_ALL(c, pt_finish_image(k, age));
     HIP_TRY(hipSetDevice(c->device));
     return pump(c, PUMP_IMAGE, (c->curImage + pt_ctx::IMAGES - age) % pt_ctx::IMAGES);
 }
 
 int pt_image_device(pt_ctx* c, int age, void** dev_ptr, size_t* n_pixels) {
     if (!c || !dev_ptr || !n_pixels || age < 0 || age >= pt_ctx::IMAGES) return fail(PT_ERR_ARG, "pt_image_device: bad argument");
+    if (c->multi) return fail(PT_ERR_ARG, "pt_image_device: a multi-GPU context has one packed accumulator per device; pt_gather_image delivers the whole image");
     float4* img = c->dImage[(c->curImage + pt_ctx::IMAGES - age) % pt_ctx::IMAGES];
     if (!img) return fail(PT_ERR_ARG, "pt_image_device: no image of that age yet (too few pt_next_image calls)");
     *dev_ptr = img; *n_pixels = (size_t)c->nSlotsImg;
@@ -1488,6 +1597,7 @@ int pt_image_device(pt_ctx* c, int age, void** dev_ptr, size_t* n_pixels) {
 
 int pt_synchronize(pt_ctx* c) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    MULTI_ALL(c, pt_synchronize(k));
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = flushStream(c))) return rc;
@@ -1497,6 +1607,15 @@ int pt_synchronize(pt_ctx* c) {
 
 int pt_read_frame(pt_ctx* c, float* out) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_read_frame: null argument");
+    if (c->multi) {                                               // the ONE collective: RCCL gather on device[0], un-tile, read back
+        float4* full = nullptr;
+        int rc = multiGather(c, 0, &full);
+        if (rc) return rc;
+        pt_ctx* root = c->multi->kids[0];
+        HIP_TRY(hipMemcpyAsync(out, full, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, root->stream));
+        HIP_TRY(hipStreamSynchronize(root->stream));
+        return PT_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     { int rc; if ((rc = flushStream(c))) return rc; }
     float4* const dFrame = c->dImage[c->curImage];
@@ -1514,22 +1633,44 @@ int pt_read_frame(pt_ctx* c, float* out) {
 
 int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out) {
     if (!c || !rgb_out) return fail(PT_ERR_ARG, "pt_read_display: null argument");
-    if (c->shardCount != 1) return fail(PT_ERR_ARG, "pt_read_display needs the whole image: gather the shards first (shard_count must be 1)");
-    HIP_TRY(hipSetDevice(c->device));
-    { int rc; if ((rc = flushStream(c))) return rc; }
-    size_t bytes = (size_t)c->W * c->H * 3;
-    unsigned char* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, bytes));
-    hipLaunchKernelGGL(k_display, dim3((unsigned)(((size_t)c->W * c->H + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->dImage[c->curImage], c->W, c->H, (float)frame_count, java_bytes, d);
-    hipError_t e = hipMemcpyAsync(rgb_out, d, bytes, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d);
-    if (e != hipSuccess) return fail(PT_ERR_HIP, std::string("pt_read_display: ") + hipGetErrorString(e));
+    const float4* frame = nullptr; pt_ctx* on = c;
+    if (c->multi) {
+        float4* full = nullptr;
+        int rc = multiGather(c, 0, &full);
+        if (rc) return rc;
+        frame = full; on = c->multi->kids[0];
+    } else {
+        if (c->shardCount != 1) return fail(PT_ERR_ARG, "pt_read_display needs the whole image: a single shard of several cannot show it (use a pt_create_multi context)");
+        HIP_TRY(hipSetDevice(c->device));
+        { int rc; if ((rc = flushStream(c))) return rc; }
+        frame = c->dImage[c->curImage];
+    }
+    HIP_TRY(hipSetDevice(on->device));
+    const size_t bytes = (size_t)c->W * c->H * 3;
+    if (!on->dDisplay) HIP_TRY(hipMalloc((void**)&on->dDisplay, bytes));
+    hipLaunchKernelGGL(k_display, dim3((unsigned)(((size_t)c->W * c->H + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, on->stream, frame, c->W, c->H, (float)frame_count, java_bytes, on->dDisplay);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rgb_out, on->dDisplay, bytes, hipMemcpyDeviceToHost, on->stream));
+    HIP_TRY(hipStreamSynchronize(on->stream));
+    return PT_OK;
+}
+
+/* One image of a multi-GPU context: finish image `age` on every device, ONE RCCL gather of the packed accumulators on device[0],
+ * un-tile there (stream-ordered on device[0]'s stream, not synchronised).  A one-device context returns its own image. */
+int pt_gather_image(pt_ctx* c, int age, void** full_dev) {
+    if (!c || !full_dev || age < 0 || age >= pt_ctx::IMAGES) return fail(PT_ERR_ARG, "pt_gather_image: bad argument");
+    if (c->multi) { float4* full = nullptr; int rc = multiGather(c, age, &full); if (rc) return rc; *full_dev = full; return PT_OK; }
+    if (c->shardCount != 1) return fail(PT_ERR_ARG, "pt_gather_image: this context is one shard of several; the gather belongs to the multi-GPU context (pt_create_multi) or to the host layer");
+    int rc = pt_finish_image(c, age);
+    if (rc) return rc;
+    *full_dev = c->dImage[(c->curImage + pt_ctx::IMAGES - age) % pt_ctx::IMAGES];
+    if (!*full_dev) return fail(PT_ERR_ARG, "pt_gather_image: no image of that age yet (too few pt_next_image calls)");
     return PT_OK;
 }
 
 int pt_frame_device(pt_ctx* c, void** dev_ptr, size_t* n_pixels) {
     if (!c || !dev_ptr || !n_pixels) return fail(PT_ERR_ARG, "pt_frame_device: null argument");
+    if (c->multi) return fail(PT_ERR_ARG, "pt_frame_device: a multi-GPU context has one packed accumulator per device; pt_gather_image delivers the whole image");
     *dev_ptr = c->dImage[c->curImage]; *n_pixels = (size_t)c->nSlotsImg;
     return PT_OK;
 }
@@ -1552,6 +1693,7 @@ int pt_shard_map(int width, int height, int shard_rank, int shard_count, int32_t
 
 int pt_unshard(pt_ctx* c, const void* gathered_dev, void* full_dev) {
     if (!c || !gathered_dev || !full_dev) return fail(PT_ERR_ARG, "pt_unshard: null argument");
+    if (c->multi) return fail(PT_ERR_ARG, "pt_unshard: a multi-GPU context gathers and un-tiles by itself (pt_gather_image, pt_read_frame)");
     HIP_TRY(hipSetDevice(c->device));
     size_t total = (size_t)c->nSlotsImg * c->shardCount;
     if (!c->dAllMaps) {
@@ -1567,6 +1709,7 @@ int pt_unshard(pt_ctx* c, const void* gathered_dev, void* full_dev) {
 
 int pt_set_stream(pt_ctx* c, void* hip_stream) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    if (c->multi) return fail(PT_ERR_ARG, "pt_set_stream: a multi-GPU context owns one stream per device");
     HIP_TRY(hipSetDevice(c->device));
     { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1576,6 +1719,7 @@ int pt_set_stream(pt_ctx* c, void* hip_stream) {
 
 int pt_set_option(pt_ctx* c, int option, int64_t value) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    MULTI_ALL(c, pt_set_option(k, option, value));
     { int rc; if ((rc = flushStream(c))) return rc; }
     switch (option) {
         case 0: if (value != 0 && (value < BLOCK || value > (1 << 26))) return fail(PT_ERR_ARG, "path slots must be 0 (automatic) or in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
@@ -1594,6 +1738,16 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
 
 int pt_get_counters(pt_ctx* c, uint64_t* out, int n) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_get_counters: null argument");
+    if (c->multi) {                                               // whole-image totals: the sum over the shards
+        for (int k = 0; k < n && k < PT_CNT_N; k++) out[k] = 0;
+        for (pt_ctx* kid : c->multi->kids) {
+            uint64_t one[PT_CNT_N] = {0};
+            int rc = pt_get_counters(kid, one, PT_CNT_N);
+            if (rc) return rc;
+            for (int k = 0; k < n && k < PT_CNT_N; k++) out[k] += one[k];
+        }
+        return PT_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1608,6 +1762,7 @@ int pt_get_counters(pt_ctx* c, uint64_t* out, int n) {
 
 int pt_reset_counters(pt_ctx* c) {
     if (!c) return fail(PT_ERR_ARG, "null context");
+    MULTI_ALL(c, pt_reset_counters(k));
     HIP_TRY(hipSetDevice(c->device));
     { int rc; if ((rc = flushStream(c))) return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1620,6 +1775,7 @@ int pt_reset_counters(pt_ctx* c) {
 
 int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_debug_phase_stats: null argument");
+    if (c->multi) c = c->multi->kids[0];
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));                     // what the launches so far left; submitted batches are NOT completed first
     Control h;
@@ -1632,10 +1788,20 @@ int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
     return PT_OK;
 }
 
-int pt_set_timing(pt_ctx* c, int enabled) { if (!c) return fail(PT_ERR_ARG, "null context"); c->timing = enabled != 0; return PT_OK; }
+int pt_set_timing(pt_ctx* c, int enabled) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    if (c->multi) { for (pt_ctx* k : c->multi->kids) k->timing = enabled != 0; return PT_OK; }
+    c->timing = enabled != 0;
+    return PT_OK;
+}
 
 int pt_kernel_time(pt_ctx* c, int kernel, int64_t* launches, double* total_ms) {
     if (!c || kernel < 0 || kernel > 3 || !launches || !total_ms) return fail(PT_ERR_ARG, "pt_kernel_time: bad argument");
+    if (c->multi) {                                               // launches and device time summed over the shards: total / launches = mean launch
+        *launches = 0; *total_ms = 0;
+        for (pt_ctx* kid : c->multi->kids) { int64_t l; double ms; int rc = pt_kernel_time(kid, kernel, &l, &ms); if (rc) return rc; *launches += l; *total_ms += ms; }
+        return PT_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = resolveTimes(c);
@@ -1646,6 +1812,7 @@ int pt_kernel_time(pt_ctx* c, int kernel, int64_t* launches, double* total_ms) {
 
 int pt_kernel_time_median(pt_ctx* c, int kernel, double* median_ms) {
     if (!c || kernel < 0 || kernel > 3 || !median_ms) return fail(PT_ERR_ARG, "pt_kernel_time_median: bad argument");
+    if (c->multi) c = c->multi->kids[0];
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int rc = resolveTimes(c);
@@ -1659,6 +1826,7 @@ int pt_kernel_time_median(pt_ctx* c, int kernel, double* median_ms) {
 
 int pt_debug_math(pt_ctx* c, int fn, const float* x, const float* y, float* out, size_t n) {
     if (!c || !x || !out) return fail(PT_ERR_ARG, "pt_debug_math: null argument");
+    if (c->multi) c = c->multi->kids[0];
     HIP_TRY(hipSetDevice(c->device));
     float *dx, *dy, *dout;
     HIP_TRY(hipMalloc((void**)&dx, n * 4)); HIP_TRY(hipMalloc((void**)&dy, n * 4)); HIP_TRY(hipMalloc((void**)&dout, n * 4));
@@ -1673,8 +1841,11 @@ int pt_debug_math(pt_ctx* c, int fn, const float* x, const float* y, float* out,
 
 int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, size_t n) {
     if (!c || !o || !d || !out || n < 1 || n > (1u << 24)) return fail(PT_ERR_ARG, "pt_debug_intersect: bad argument");
+    if (c->multi) c = c->multi->kids[0];
     HIP_TRY(hipSetDevice(c->device));
     int rc;
+    if ((rc = flushStream(c))) return rc;                         // before the frame constants of a running stream are overwritten
+    std::memset(&c->streamIn, 0xff, sizeof(FrameIn));             // ... which are no stream's any more afterwards
     if (c->sceneDirty && (rc = buildScene(c))) return rc;
     size_t np = (n + BLOCK - 1) / BLOCK * BLOCK;
     std::vector<float> g0(np * 4, 0.0f), g1(np * 4, 0.0f);
@@ -1693,7 +1864,6 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     HIP_TRY(hipMemcpy(c->dFrameIn, &fin, sizeof(fin), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, c->stream, c->sc, c->dFrameIn, c->dFc, c->dEllip);
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
-    { int rc2; if ((rc2 = flushStream(c))) return rc2; }
     hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, c->stream, c->dCtl);
     hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, 0, (int)np, c->dCtl);
     HIP_TRY(hipStreamSynchronize(c->stream));

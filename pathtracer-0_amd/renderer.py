@@ -31,6 +31,8 @@ def lib():
         vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
         L.pt_last_error.restype = C.c_char_p
         L.pt_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
+        L.pt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(ci), ci, ci, ci]
+        L.pt_gather_image.argtypes = [vp, ci, C.POINTER(vp)]
         L.pt_destroy.argtypes = [vp]
         L.pt_set_buffer.argtypes = [vp, ci, vp, sz]
         L.pt_set_texture.argtypes = [vp, ci, ci, ci, vp]
@@ -88,11 +90,20 @@ def shard_map(W, H, rank, count):
 
 
 class Renderer:
-    def __init__(self, W, H, device=0, shard_rank=0, shard_count=1):
+    """One render context.  `devices=[...]`: ONE context for several GPUs (pt_create_multi): the tile shards, the per-device host
+    threads and the RCCL gather of every image live inside the library; a device listed twice rehearses the sharding on one GPU."""
+
+    def __init__(self, W, H, device=0, shard_rank=0, shard_count=1, devices=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.W, self.H, self.shard_rank, self.shard_count = W, H, shard_rank, shard_count
-        _check(self._L.pt_create(C.byref(self._h), device, W, H, shard_rank, shard_count))
+        self.devices = None if devices is None else [int(d) for d in devices]
+        if self.devices is not None:
+            assert shard_count == 1 and shard_rank == 0, "a multi-GPU context shards by itself"
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            _check(self._L.pt_create_multi(C.byref(self._h), arr, len(self.devices), W, H))
+        else:
+            _check(self._L.pt_create(C.byref(self._h), device, W, H, shard_rank, shard_count))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -149,6 +160,13 @@ class Renderer:
         p, n = C.c_void_p(), C.c_size_t()
         _check(self._L.pt_image_device(self._h, int(age), C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def gather_image(self, age=0):
+        """Device pointer of the whole W x H RGBA32F image `age` images ago: on a multi-GPU context this is the ONE RCCL gather
+        + un-tiling on devices[0] (stream-ordered there, not synchronised)."""
+        p = C.c_void_p()
+        _check(self._L.pt_gather_image(self._h, int(age), C.byref(p)))
+        return p.value
 
     def synchronize(self):
         _check(self._L.pt_synchronize(self._h))

@@ -1,4 +1,6 @@
-"""Multi-GPU image sharding: one process per GPU, one RCCL collective per sample batch.
+"""Multi-GPU image sharding, process-per-GPU form: one RCCL collective per sample batch.
+
+(The single-process form lives inside the library: pt_create_multi / pt_gather_image, csrc/hip/pt_multi.hpp.)
 
 Every pixel-frame lane is independent (shared read-only scene, RNG keyed on the GLOBAL pixel
 index, /root/reference/src/shaders/frag.glsl:886,896), so the image is cut into 32x8 tiles dealt
@@ -31,29 +33,39 @@ def all_maps(W, H, world, shard_map_fn):
 
 
 class Unsharder:
-    """Precomputed un-tiling: packed slot -> global pixel, built once so a step issues no host sync."""
+    """Un-tiling of the gathered accumulators: packed slot -> global pixel.  On the GPU this is the library's own kernel
+    (pt_unshard / k_unshard on the renderer's stream, the same one the multi-GPU context runs after its ncclGather); the torch
+    index form is what the CPU (gloo) tests exercise."""
 
-    def __init__(self, W, H, world, shard_map_fn, device):
+    def __init__(self, W, H, world, shard_map_fn, device, renderer=None):
         maps = torch.from_numpy(all_maps(W, H, world, shard_map_fn).astype(np.int64))
         self.W, self.H, self.world = W, H, world
+        self.renderer = renderer if torch.device(device).type == "cuda" else None
         self.src = torch.nonzero(maps >= 0).squeeze(1).to(device)          # packed slots that carry a pixel
         self.dst = maps[maps >= 0].to(device)                               # their global pixel indices
         self.identity = world == 1 and bool((self.src.cpu() == self.dst.cpu()).all())
+        self._full = None
 
     def __call__(self, gathered):
         if self.identity:
             return gathered[: self.W * self.H].reshape(self.H, self.W, 4)
+        if self.renderer is not None and gathered.is_cuda:
+            if self._full is None:
+                self._full = torch.empty((self.H * self.W, 4), dtype=gathered.dtype, device=gathered.device)
+            self.renderer.unshard(gathered.data_ptr(), self._full.data_ptr())      # stream-ordered on the renderer's stream (= torch's current one)
+            return self._full.reshape(self.H, self.W, 4)
         full = torch.empty((self.H * self.W, 4), dtype=gathered.dtype, device=gathered.device)
         full.index_copy_(0, self.dst, gathered.index_select(0, self.src))
         return full.reshape(self.H, self.W, 4)
 
 
-def gather_frame(packed, unsharder, dst=0, group=None):
+def gather_frame(packed, unsharder, dst=0, group=None, force_collective=False):
     """ONE collective: gather every rank's packed accumulator (n_slots,4) on `dst`, then un-tile.
 
-    Returns the full (H, W, 4) image on rank `dst`, None elsewhere."""
+    Returns the full (H, W, 4) image on rank `dst`, None elsewhere.  force_collective: issue the gather even in a world of one
+    (bench.py --dist: the RCCL call path of the process-per-GPU form, exercised on a one-GPU box)."""
     world = unsharder.world
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return unsharder(packed)
     rank = dist.get_rank(group)
     if rank == dst:
@@ -69,15 +81,19 @@ class StepPipeline:
     asynchronously; the image is completed and gathered LAG steps later, when its last paths have long retired, so neither the
     path pool nor the collective ever waits for a straggler.  `drain()` completes and gathers what is still in flight."""
 
-    def __init__(self, renderer, unsharder, device, lag=2, dst=0, group=None, tensor_of=None):
+    def __init__(self, renderer, unsharder, device, lag=2, dst=0, group=None, tensor_of=None, collect=None, force_collective=False):
         assert 0 <= lag <= 3, "the library keeps a ring of four FRAME images"
         self.r, self.unsharder, self.device, self.lag, self.dst, self.group = renderer, unsharder, device, lag, dst, group
         self.tensor_of = tensor_of or (lambda r, age: frame_tensor(r, device, age))
+        self.collect = collect          # collect(age) -> image: a multi-GPU context gathers inside the library (pt_gather_image)
+        self.force_collective = force_collective
         self.in_flight = 0
 
     def _collect(self, age):
+        if self.collect is not None:
+            return self.collect(age)
         self.r.finish_image(age)
-        return gather_frame(self.tensor_of(self.r, age), self.unsharder, dst=self.dst, group=self.group)
+        return gather_frame(self.tensor_of(self.r, age), self.unsharder, dst=self.dst, group=self.group, force_collective=self.force_collective)
 
     def step(self, submit):
         """submit(): the step's pt_render_batch_async calls.  Returns the gathered image of the step LAG steps ago (rank dst), else None."""

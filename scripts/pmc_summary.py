@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Condenses the counter passes of scripts/pmc_all.sh into summary.json (+ a text table on stdout).
+
+usage: pmc_summary.py gpurun_out/<tag> <config> <frames-per-step>
+
+Per kernel: counter totals over all launches of a pass, and the figures bench.py's `roofline` block is built from:
+  valu_per_segment   SQ_INSTS_VALU / segments                (wave-instructions; a v_pk_* counts once)
+  salu_per_segment   SQ_INSTS_SALU / segments
+  lane_util          SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)   lanes busy per issued VALU instruction
+  wait_share         SQ_WAIT_ANY / SQ_WAVE_CYCLES            wave parked in s_waitcnt / barrier
+  issue_stall_share  SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES       wave ready, issue port taken
+  active_share       SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
+  hbm_bytes_per_segment   (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 / segments   (gfx950: FETCH_SIZE tallies 128-B requests as 64 B,
+                           /opt/skills/guides/MI355X_MICROARCH.md, HBM)
+segments = W * H * SAMPLE_RES * frames-per-step * 2 passes (bench.py's untimed set-up pass + 1 timed step) * S, with S = segments per
+sample from the statistics pass of the un-profiled run of the same command (plain.json; deterministic per scene and seeds).
+VALU issue roof: 256 CUs * 4 SIMDs * 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 wave-instructions/s.
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+VALU_PEAK = 256 * 4 * 2.4e9 / 2
+HBM_PEAK = 8.0e12
+
+
+def main(d, cfg, fps):
+    plain = None
+    for l in open(f"{d}/plain.json").read().splitlines():
+        if l.startswith("{"):
+            plain = json.loads(l)
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for f in glob.glob(f"{d}/set*/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            m = re.search(r"(k_[a-z_]+)", row["Kernel_Name"])
+            k = m.group(1) if m else "other"
+            a = agg[k][row["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+    out = {"source": d, "config": cfg, "frames_per_step": fps, "command": f"rocprofv3 --pmc <set> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 "
+           f"--frames-per-step {fps} --no-cpu-baseline --no-roofline", "valu_issue_peak_per_s": VALU_PEAK, "kernels": {}}
+    if plain:
+        rf = plain.get("roofline", {})
+        W, H = plain["config"]["width"], plain["config"]["height"]
+        S = rf.get("segments_per_sample")
+        sres = plain["config"]["spp_per_step"] // fps
+        seg = W * H * sres * fps * 2 * S
+        out.update({"segments_per_sample": S, "segments_in_a_pass": seg, "plain_run": {"value": plain["value"], "ms_per_step": plain["ms_per_step"],
+                    "extend_avg_launch_ms": rf.get("avg_launch_ms"), "shade_avg_launch_ms": rf.get("shade_avg_launch_ms"), "extend_launches": rf.get("launches"),
+                    "per_segment": rf.get("per_segment")}})
+    else:
+        seg = None
+    for k, v in sorted(agg.items()):
+        if k not in ("k_extend_persist", "k_extend", "k_shade", "k_accumulate", "k_revive"):
+            continue
+        tot = {c: x[1] for c, x in v.items()}
+        n = max(x[0] for x in v.values())
+        o = {"launches_per_pass": n, "totals": {c: round(x) for c, x in sorted(tot.items())}}
+        g = tot.get
+        if seg and k in ("k_extend_persist", "k_extend", "k_shade"):
+            if g("SQ_INSTS_VALU"):
+                o["valu_per_segment"] = round(g("SQ_INSTS_VALU") / seg, 3)
+                o["salu_per_segment"] = round(g("SQ_INSTS_SALU", 0) / seg, 3)
+                o["lds_insts_per_segment"] = round(g("SQ_INSTS_LDS", 0) / seg, 3)
+            if g("SQ_INSTS_VMEM_RD") is not None and g("SQ_INSTS_VMEM_RD"):
+                o["vmem_rd_per_segment"] = round(g("SQ_INSTS_VMEM_RD") / seg, 3)
+                o["vmem_wr_per_segment"] = round(g("SQ_INSTS_VMEM_WR", 0) / seg, 3)
+            if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+                o["hbm_fetch_bytes_per_segment_x2"] = round(2 * g("FETCH_SIZE") * 1024 / seg, 2)
+                o["hbm_write_bytes_per_segment"] = round(g("WRITE_SIZE") * 1024 / seg, 2)
+                o["hbm_bytes_per_segment"] = round((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / seg, 2)
+        if g("SQ_ACTIVE_INST_VALU"):
+            o["lane_util"] = round(g("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4)
+        if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
+            pass
+        out["kernels"][k] = o
+    # shares need SQ_WAVE_CYCLES from set 1 and the wait counters from set 2: both are totals of the same launches
+    for k, o in out["kernels"].items():
+        t = o["totals"]
+        wc = t.get("SQ_WAVE_CYCLES")
+        if wc:
+            for name, c in (("wait_share", "SQ_WAIT_ANY"), ("issue_stall_share", "SQ_WAIT_INST_ANY"), ("active_share", "SQ_ACTIVE_INST_ANY"),
+                            ("valu_active_share", "SQ_ACTIVE_INST_VALU"), ("scalar_active_share", "SQ_ACTIVE_INST_SCA")):
+                if c in t:
+                    o[name] = round(t[c] / wc, 4)
+    if plain and "k_extend_persist" in out["kernels"]:
+        o = out["kernels"]["k_extend_persist"]
+        pr = out["plain_run"]
+        if pr["extend_avg_launch_ms"] and pr["extend_launches"] and "valu_per_segment" in o:
+            seg_rate = (seg / 2.0) / (pr["extend_avg_launch_ms"] * 1e-3 * pr["extend_launches"])      # segments/s while the kernel runs (timed step of the plain run)
+            o["segments_per_s_in_kernel"] = seg_rate
+            o["valu_issue_frac"] = round(o["valu_per_segment"] * seg_rate / VALU_PEAK, 4)
+            if "hbm_bytes_per_segment" in o:
+                o["hbm_frac"] = round(o["hbm_bytes_per_segment"] * seg_rate / HBM_PEAK, 4)
+    json.dump(out, open(f"{d}/summary.json", "w"), indent=1)
+    print(f"# counter summary {cfg} ({d}); segments per pass = {seg}")
+    for k, o in out["kernels"].items():
+        print(k, json.dumps({a: b for a, b in o.items() if a != "totals"}))
+        print("   totals", json.dumps(o["totals"]))
+    if plain:
+        print("plain run:", json.dumps(out["plain_run"]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]))
