@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--devices", default=None, help="single-process multi-GPU context on these HIP devices, e.g. 0,1,2,3 (default 0..N-1); a device listed "
                                                     "twice (0,0) rehearses the sharding on one GPU (gather by device copies: RCCL refuses duplicate devices)")
     ap.add_argument("--dist", action="store_true", help="take the torch.distributed path even at WORLD_SIZE 1 (exercises the RCCL gather of the process-per-GPU form on one GPU)")
-    for name in ("lds-budget", "extend-mode", "extend-tpb", "extend-cache", "refill-min", "none-min", "extend-blocks-per-cu", "inner-keep"):
+    for name in ("lds-budget", "extend-mode", "extend-tpb", "extend-cache", "refill-min", "none-min", "extend-blocks-per-cu", "inner-keep", "bfs-nodes", "stack-mode"):
         ap.add_argument("--" + name, type=int, default=None)
     ap.add_argument("--rehearse-shard", type=int, nargs=2, metavar=("RANK", "COUNT"), default=None,
                     help="single-process rehearsal of ONE tile shard of a COUNT-GPU run (no collective); reports that shard's rate")
@@ -162,7 +162,7 @@ def main():
     if args.path_slots:
         r.set_option("path_slots", args.path_slots)
     for name, val in (("lds_budget", args.lds_budget), ("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache),
-                      ("refill_min", args.refill_min), ("none_min", args.none_min), ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep)):
+                      ("refill_min", args.refill_min), ("none_min", args.none_min), ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep), ("bfs_nodes", args.bfs_nodes), ("stack_mode", args.stack_mode)):
         if val is not None:
             r.set_option(name, val)
     if not multi:
@@ -313,7 +313,7 @@ def main():
             src = r
         out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res)
 
-    if rank == 0 and n_gpus == 1 and shards == 1 and not dist_mode and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and shards == 1 and not dist_mode and not multi and not args.no_cpu_baseline:
         # the reference has no CPU render path: the timed CPU baseline is the oracle ("port")
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle

@@ -31,7 +31,7 @@ enum {
     PT_ERR_SCENE = -4,      /* scene buffers inconsistent (index out of range, BVH deeper than the
                                reference's int stack[64] (frag.glsl:465), ...) */
     PT_ERR_UNSUPPORTED = -5 /* feature the reference has but SURVEY.md §2/§8(f) scopes out
-                               (DEBUG, implicits, texture-mapped materials on ellipsoids) */
+                               (implicit surfaces: dead code in the reference) */
 };
 
 /* SSBO binding points of frag.glsl:14-77 accepted by pt_set_buffer */

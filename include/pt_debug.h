@@ -15,7 +15,9 @@ extern "C" {
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on the blocks per CU of the persistent grid (default 4 = 8 waves per SIMD; never more than fit at once; 0 = no cap),
- * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6) */
+ * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6),
+ * 10 = inner-node records kept in breadth-first order (whole levels, the top of the trees); deeper ones are laid out depth-first,
+ * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 32-bit; -1 = automatic */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 
 /* Per-kernel device time since pt_set_timing(1) / pt_reset_counters, measured with HIP events on the

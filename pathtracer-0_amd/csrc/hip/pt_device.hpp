@@ -104,52 +104,6 @@ PM_DEV void rayBox2(vec3 o, vec3 invD, float4 q0, float4 q1, float4 q2, float& L
     }
 }
 
-// rayBox2 on a ray kept as three register pairs: oxy = (o.x, o.y), ozi = (o.z, 1/d.z), ixy = (1/d.x, 1/d.y).  The packed
-// instructions broadcast one half of a pair to both results through op_sel, so no (o.x, o.x) ... duplicates have to be built in
-// registers (the compiler builds them with v_mov pairs at every phase entry).  Same twelve IEEE operations as rayBox2.
-PM_DEV void rayBox2p(f32x2 oxy, f32x2 ozi, f32x2 ixy, float4 q0, float4 q1, float4 q2, float& Ld, float& Rd) {
-    f32x2 a0 = {q0.x, q0.y}, a1 = {q0.z, q0.w}, a2 = {q1.x, q1.y}, a3 = {q1.z, q1.w}, a4 = {q2.x, q2.y}, a5 = {q2.z, q2.w};
-    f32x2 tminx, tminy, tminz, tmaxx, tmaxy, tmaxz;
-#define PK_SUB_LO(d, a, b) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
-#define PK_SUB_HI(d, a, b) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b))
-#define PK_MUL_LO(d, a, b) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b))
-#define PK_MUL_HI(d, a, b) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b))
-    PK_SUB_LO(tminx, a0, oxy); PK_SUB_HI(tminy, a1, oxy); PK_SUB_LO(tminz, a2, ozi);
-    PK_SUB_LO(tmaxx, a3, oxy); PK_SUB_HI(tmaxy, a4, oxy); PK_SUB_LO(tmaxz, a5, ozi);
-    PK_MUL_LO(tminx, tminx, ixy); PK_MUL_HI(tminy, tminy, ixy); PK_MUL_HI(tminz, tminz, ozi);
-    PK_MUL_LO(tmaxx, tmaxx, ixy); PK_MUL_HI(tmaxy, tmaxy, ixy); PK_MUL_HI(tmaxz, tmaxz, ozi);
-#undef PK_SUB_LO
-#undef PK_SUB_HI
-#undef PK_MUL_LO
-#undef PK_MUL_HI
-    // the slab min/max as written instructions too: the compiler cannot know that an asm result is a canonical float and would
-    // put a canonicalising v_max_f32 x, x, x in front of every minnum/maxnum (v_min_f32 / v_max_f32 ARE minNum / maxNum)
-#define V_MIN(d, a, b) asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
-#define V_MAX(d, a, b) asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
-#define V_MAX3(d, a, b, c) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#define V_MIN3(d, a, b, c) asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
-    {
-        float t1x, t1y, t1z, t2x, t2y, t2z, tNear, tFar, tN0;
-        V_MIN(t1x, tminx.x, tmaxx.x); V_MIN(t1y, tminy.x, tmaxy.x); V_MIN(t1z, tminz.x, tmaxz.x);
-        V_MAX(t2x, tminx.x, tmaxx.x); V_MAX(t2y, tminy.x, tmaxy.x); V_MAX(t2z, tminz.x, tmaxz.x);
-        V_MAX3(tNear, t1x, t1y, t1z); V_MIN3(tFar, t2x, t2y, t2z);
-        asm("v_max_f32 %0, 0, %1" : "=v"(tN0) : "v"(tNear));                  // tNear > 0 ? tNear : 0 (a NaN tNear gives 0 either way)
-        Ld = (tFar >= tNear && tFar > 0.0f) ? tN0 : 1e30f;
-    }
-    {
-        float t1x, t1y, t1z, t2x, t2y, t2z, tNear, tFar, tN0;
-        V_MIN(t1x, tminx.y, tmaxx.y); V_MIN(t1y, tminy.y, tmaxy.y); V_MIN(t1z, tminz.y, tmaxz.y);
-        V_MAX(t2x, tminx.y, tmaxx.y); V_MAX(t2y, tminy.y, tmaxy.y); V_MAX(t2z, tminz.y, tmaxz.y);
-        V_MAX3(tNear, t1x, t1y, t1z); V_MIN3(tFar, t2x, t2y, t2z);
-        asm("v_max_f32 %0, 0, %1" : "=v"(tN0) : "v"(tNear));
-        Rd = (tFar >= tNear && tFar > 0.0f) ? tN0 : 1e30f;
-    }
-#undef V_MIN
-#undef V_MAX
-#undef V_MAX3
-#undef V_MIN3
-}
-
 // Moeller-Trumbore exactly as rayTri; returns 1e30 in t on a miss
 PM_DEV void rayTri(vec3 o, vec3 d, vec3 v1, vec3 e1, vec3 e2, float& t, float& u, float& v) {
     const float EPSILON = 1e-10f;
@@ -217,7 +171,7 @@ PM_DEV void loadTri(const DevScene& sc, const float4* ldsT, int ti, float4& t0, 
 // only at push time; strict '<' on hits), so counters equal the oracle's.
 template <bool COUNT>
 PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int stride, const float4* ldsN, const float4* ldsT,
-                           float& outT, float& outU, float& outV, int& outPrim, Counters& cnt, bool probe = false, int probeObj = 0) {
+                           float& outT, float& outU, float& outV, int& outPrim, Counters& cnt, bool probe = false, int probeObj = 0, float4* hx = nullptr) {
     vec3 o = probe ? oIn : madd(d, 1e-4f, oIn);                    // o = o + 1e-4*d  (:549); the thickness probe calls rayBVH directly (:668)
     vec3 invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     float closest = 1e30f, hu = 0.0f, hv = 0.0f;
@@ -277,7 +231,12 @@ PM_DEV void intersectScene(const DevScene& sc, vec3 oIn, vec3 d, int* stk, int s
         if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), c, E.r, E.st[0], E.st[1], E.st[2]);
         else t = rayEllipsoid(o, d, c, E.r, E.st[0], E.st[1], E.st[2]);
         if (t < closest) {                                          // hit.parentID keeps the BVH of the last triangle hit (:573): park that
-            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) hu = __int_as_float(prim);   // triangle id in u (unused for ellipsoids)
+            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) {
+                // ... and hitUV keeps that triangle's uv (:574 is not undone by :619-630): scenes whose ellipsoids carry texture-mapped
+                // materials get the triangle's (u, v, id) in a side record, mapMtl (:826) samples there
+                if (hx) *hx = make_float4(hu, hv, __int_as_float(prim), 0.0f);
+                hu = __int_as_float(prim);                          // triangle id in u (unused for ellipsoids)
+            }
             closest = t; prim = PRIM_ELLIPSOID | i;
         }
     }
@@ -307,10 +266,15 @@ PM_DEV vec3 randLambertianDistVec(uint32_t& st) {
 // ------------------------------------------------------------------------------------------------
 // Path state of one lane (registers); stored SoA in groups of float4 (see pt_hip.hip)
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t FL_INOBJ = 1u << 20, FL_APPLYABS = 1u << 21, FL_ALIVE = 1u << 31;
+// flags word of a path slot (G1.w): bits 0-11 bounce, 12-23 sample (the loop counters of frag.glsl:820 / :898; their bounds are
+// floats in the shader, here up to 4095), 24-27 size of the refraction-index stack (0..10), then the booleans
+constexpr uint32_t FL_COUNT_MASK = 0xfffu; constexpr int FL_SAMPLE_SHIFT = 12, FL_STACK_SHIFT = 24;
+constexpr uint32_t FL_INOBJ = 1u << 28, FL_APPLYABS = 1u << 29, FL_PROBE = 1u << 30, FL_ALIVE = 1u << 31;
 // directDiffuse's thickness probe (frag.glsl:668): the ray starts ON the hit point (no 1e-4 offset) and traverses only the BVH
-// of the object that was hit; the object index rides in bits 24-30
-constexpr uint32_t FL_PROBE = 1u << 22; constexpr int FL_PROBE_OBJ_SHIFT = 24; constexpr uint32_t FL_PROBE_OBJ_MASK = 0x7fu;
+// of the object that was hit.  Probes exist in the RAYTRACING == 0 mode only, where the bounce counter and the index stack are
+// not in use: while FL_PROBE is set their 16 bits (0-11 and 24-27) carry the object index.
+constexpr int FL_PROBE_OBJ_MAX = 0xffff;
+PM_DEV int probeObjOf(uint32_t f) { return (int)((f & FL_COUNT_MASK) | (((f >> FL_STACK_SHIFT) & 0xfu) << 12)); }
 
 struct Path {
     vec3 O, D;             // current ray
@@ -326,13 +290,14 @@ struct Path {
 };
 
 PM_DEV uint32_t packFlags(const Path& p) {
-    return (uint32_t)p.bounce | ((uint32_t)p.sample << 8) | ((uint32_t)p.stackSize << 16) | (p.inObj ? FL_INOBJ : 0u) |
-           (p.applyAbs ? FL_APPLYABS : 0u) | (p.alive ? FL_ALIVE : 0u) | (p.probe ? (FL_PROBE | ((uint32_t)p.probeObj << FL_PROBE_OBJ_SHIFT)) : 0u);
+    const uint32_t lo = p.probe ? ((uint32_t)p.probeObj & FL_COUNT_MASK) : (uint32_t)p.bounce, st = p.probe ? ((uint32_t)p.probeObj >> 12) : (uint32_t)p.stackSize;
+    return lo | ((uint32_t)p.sample << FL_SAMPLE_SHIFT) | (st << FL_STACK_SHIFT) | (p.inObj ? FL_INOBJ : 0u) |
+           (p.applyAbs ? FL_APPLYABS : 0u) | (p.alive ? FL_ALIVE : 0u) | (p.probe ? FL_PROBE : 0u);
 }
 PM_DEV void unpackFlags(Path& p, uint32_t f) {
-    p.bounce = f & 0xff; p.sample = (f >> 8) & 0xff; p.stackSize = (f >> 16) & 0xf;
+    p.bounce = f & FL_COUNT_MASK; p.sample = (f >> FL_SAMPLE_SHIFT) & FL_COUNT_MASK; p.stackSize = (f >> FL_STACK_SHIFT) & 0xf;
     p.inObj = f & FL_INOBJ; p.applyAbs = f & FL_APPLYABS; p.alive = f & FL_ALIVE;
-    p.probe = f & FL_PROBE; p.probeObj = (int)((f >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK);
+    p.probe = f & FL_PROBE; p.probeObj = p.probe ? probeObjOf(f) : 0;
 }
 
 // index stack, frag.glsl:139-158, as a shift array with static indices (stale slots stay readable)
@@ -384,6 +349,16 @@ PM_DEV void hitUV(const float4* S, float hu, float hv, float& uvx, float& uvy) {
         uvy = s2.y * hu + s3.x * hv + w * vt1y;
         uvy = 1.0f - uvy;
     } else { uvx = -1.0f; uvy = -1.0f; }
+}
+// hit.uvSample of any hit: a triangle's own uv; an ellipsoid's is the uv of the closest triangle the BVH loop found before it
+// (hitUV is only ever written at :574), vec2(0) when there was none (:559)
+PM_DEV void uvOfHit(const DevScene& sc, int prim, float hu, float hv, const float4* HX, unsigned slot, float& uvx, float& uvy) {
+    if (prim & PRIM_ELLIPSOID) {
+        const float4 x = HX[slot];
+        const int tp = __float_as_int(x.z);
+        if (tp >= 0) hitUV(sc.shade + 4 * (size_t)tp, x.x, x.y, uvx, uvy);
+        else { uvx = 0.0f; uvy = 0.0f; }
+    } else hitUV(sc.shade + 4 * (size_t)prim, hu, hv, uvx, uvy);
 }
 // mapMtl (frag.glsl:210-225) on the fields the render path reads, and the raw-texel normal of :827
 PM_DEV void applyMaps(const DevScene& sc, MatRec& m, float u, float v, vec3& N) {
@@ -490,7 +465,7 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
 // One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
 // Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
 template <bool TRANS, bool TEX>
-PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, unsigned slot) {
+PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, const float4* HX, unsigned slot) {
     p.bounce++;                                               // :821
     const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
     const vec3 D = p.D;
@@ -515,9 +490,9 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
             mat = __float_as_int(s2.w);
         }
         MatRec m = sc.mats[mat];
-        if (TEX && m.hasMaps) {                               // mapMtl + map_norm (:826-827); ellipsoids with mapped materials are rejected at upload
+        if (TEX && m.hasMaps) {                               // mapMtl + map_norm (:826-827)
             float uvx, uvy;
-            hitUV(sc.shade + 4 * (size_t)prim, hu, hv, uvx, uvy);
+            uvOfHit(sc, prim, hu, hv, HX, slot, uvx, uvy);
             applyMaps(sc, m, uvx, uvy, N);
         }
         p.O = loc;                                            // :824
@@ -574,7 +549,7 @@ PM_DEV vec3 subsurfaceTint(const MatRec& m, vec3 o, vec3 loc) {
     return exp3((-sigma_t) * si) * v3(m.ssColor[0], m.ssColor[1], m.ssColor[2]);                          // :672
 }
 template <bool TEX>
-PM_DEV bool directSegment(const DevScene& sc, Path& p, float ht, float hu, float hv, int prim) {
+PM_DEV bool directSegment(const DevScene& sc, Path& p, float ht, float hu, float hv, int prim, const float4* HX, unsigned slot) {
     if (p.probe) {                                            // second half of a subsurface sample: .loc of rayBVH is its (t,u,v) triple (:493)
         const MatRec m = sc.mats[__float_as_int(p.inc.x)];
         vec3 loc = (prim != PRIM_NONE) ? v3(ht, hu, hv) : v3(1e30f);
@@ -605,7 +580,7 @@ PM_DEV bool directSegment(const DevScene& sc, Path& p, float ht, float hu, float
     MatRec m = sc.mats[mat];
     if (TEX && m.hasMaps) {
         float uvx, uvy;
-        hitUV(sc.shade + 4 * (size_t)prim, hu, hv, uvx, uvy);
+        uvOfHit(sc, prim, hu, hv, HX, slot, uvx, uvy);
         applyMaps(sc, m, uvx, uvy, N);
     }
     vec3 Kd = v3(m.Kd[0], m.Kd[1], m.Kd[2]);

@@ -78,6 +78,7 @@ __device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return c
 
 struct State {              // SoA path pool, float4 groups (see header comment)
     float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *S1, *S2, *H;
+    float4* HX;             // (u, v, id) of the closest triangle behind an ellipsoid hit; only for scenes whose ellipsoids carry texture-mapped materials
 };
 
 // The frame stream: consecutive batches with the same frame inputs (Parameters, ORIGIN, ROTATION, MOUSE_POS) form ONE job
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
     float t, u, v; int prim; Counters c;
     const unsigned fl = __float_as_uint(g1.w);
     intersectScene<COUNT>(sc, v3(g0.x, g0.y, g0.z), v3(g0.w, g1.x, g1.y), stkBase + threadIdx.x, BLOCK, ldsN, ldsT, t, u, v, prim, c,
-                          (fl & FL_PROBE) != 0, (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK));
+                          (fl & FL_PROBE) != 0, probeObjOf(fl), st.HX ? st.HX + i : nullptr);
     st.H[i] = make_float4(t, u, v, __int_as_float(prim));
     if (COUNT) {
         atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
@@ -269,6 +270,13 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 // (activity is folded into `cur` so that every wave-level vote is ONE v_cmp writing an SGPR pair)
 constexpr int CUR_NONE = 0x7ffffffe;
 constexpr int CUR_IDLE = 0x7fffffff;
+// Traversal-stack entries (pending far children) live in LDS, one column per lane.  Their width decides how many blocks a CU holds:
+//   short     trees below 32767 inner nodes / triangle records
+//   Packed18  up to 131071: the low 16 bits in LDS, bits 16-17 in a per-lane shift register (two VGPRs, 2 bits per level, 32 levels)
+//   int       anything larger
+struct Packed18 {};
+template <typename T> struct StackElem { typedef T type; };
+template <> struct StackElem<Packed18> { typedef unsigned short type; };
 
 #ifndef PT_EP_WAVES
 #define PT_EP_WAVES 8        // waves per SIMD the register allocation must leave room for (4 blocks of 512 threads per CU)
@@ -277,19 +285,18 @@ template <bool COUNT, typename StackT, int TPB, bool PROBES>
 __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
                                                        Control* ctl, int refillMin, int keepEighths, int nObjLds, int noneMin) {
     extern __shared__ float4 smem[];
+    typedef typename StackElem<StackT>::type ElemT;
+    constexpr bool PACKED = __is_same(StackT, Packed18);
+    unsigned hiA = 0u, hiB = 0u;                                   // Packed18: bits 16-17 of the stacked entries, newest in hiA[1:0]
     float4* ldsN = smem;
     float4* ldsT = smem + 4 * sc.ldsNodes;
     // per-lane root-box distances (rayNode(o,d,root) of :468 depends on the ray only, so it is evaluated once per ray
     // when the lane takes the ray — all refilled lanes together — and only compared against `closest` later)
     float* rootDist = reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + threadIdx.x;
-#ifdef PT_V_ROOTS_LDS
     // the first nObjLds object roots (box + reference, 32 B each) are read by every refill and every next-object step: LDS copies
     float4* rootsL = reinterpret_cast<float4*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB);
-    StackT* stk = reinterpret_cast<StackT*>(rootsL + 2 * nObjLds) + threadIdx.x;
+    ElemT* stk = reinterpret_cast<ElemT*>(rootsL + 2 * nObjLds) + threadIdx.x;
     for (int k = threadIdx.x; k < 2 * nObjLds; k += TPB) rootsL[k] = reinterpret_cast<const float4*>(sc.roots)[k];
-#else
-    StackT* stk = reinterpret_cast<StackT*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB) + threadIdx.x;
-#endif
     for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += TPB) ldsN[k] = sc.nodes[k];
     for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += TPB) ldsT[k] = sc.tris[k];
     __syncthreads();
@@ -301,19 +308,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
     const unsigned per = (((n + nWaves - 1) / nWaves) + 63u) & ~63u;       // static range of this wave, 64-aligned -> coalesced first fill
     unsigned pos = waveId * per;
     const unsigned end = min(pos + per, n);
-#ifdef PT_V_OPSEL
-    // the ray as three aligned register pairs (rayBox2p): o = (oxy.x, oxy.y, ozi.x), 1/d = (ixy.x, ixy.y, ozi.y)
-    f32x2 oxy = {0.0f, 0.0f}, ozi = {0.0f, 0.0f}, ixy = {0.0f, 0.0f};
-#define RAY_O v3(oxy.x, oxy.y, ozi.x)
-#define RAY_INVD v3(ixy.x, ixy.y, ozi.y)
-#define RAYBOX2(q0, q1, q2, a, b) rayBox2p(oxy, ozi, ixy, q0, q1, q2, a, b)
-    vec3 d = v3(0.0f);
-#else
     vec3 o = v3(0.0f), d = v3(0.0f), invD = v3(0.0f);
-#define RAY_O o
-#define RAY_INVD invD
-#define RAYBOX2(q0, q1, q2, a, b) rayBox2(o, invD, q0, q1, q2, a, b)
-#endif
     float closest = 1e30f, hu = 0.0f, hv = 0.0f;
     int prim = PRIM_NONE, ob = 0, obEnd = 0, sp = 0, cur = CUR_IDLE;
     bool probe = false;
@@ -328,6 +323,161 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 #else
 #define PS(k, lanes) do { } while (0)
 #endif
+#ifdef PT_V_FLAT
+    // ONE loop whose trip runs ONE phase, named by the wave-uniform `mode`: every per-lane variable is carried around a single back
+    // edge (nested phase loops made the compiler move cur / sp / ob / closest / hu / hv / prim between register sets at every loop
+    // boundary: about a fifth of the kernel's vector instructions were such copies).
+    enum { M_VOTE = 0, M_REFILL, M_NONE, M_INNER, M_LEAF };
+    int mode = M_VOTE, thr = 0, nIdle = 0;
+    unsigned long long idle = 0;
+    for (;;) {
+        if (mode == M_VOTE) {
+            idle = __ballot(cur == CUR_IDLE);
+            nIdle = __popcll(idle);
+            PS(4, 64 - nIdle);
+            if (pos < end && nIdle >= refillMin) mode = M_REFILL;          // idle lanes take the next rays of the wave's range
+            else {
+                if (nIdle == 64) break;                                      // the range is used up and every ray has retired
+                const int nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
+                const int nLeaf = __popcll(__ballot(cur < 0));
+                const int nNone = 64 - nIdle - nInner - nLeaf;
+                // the next-object / retire step is worth a trip for noneMin lanes, or when it is the most wanted of the three
+                if (nNone >= noneMin || (nNone > 0 && nNone >= nInner && nNone >= nLeaf)) mode = M_NONE;
+                else if (nInner >= nLeaf) { mode = M_INNER; thr = (nInner * keepEighths) >> 3; }
+                else { mode = M_LEAF; thr = (nLeaf * keepEighths) >> 3; }
+            }
+        }
+        if (mode == M_REFILL) {
+            PS(0, min(nIdle, (int)(end - pos)));
+            if (cur == CUR_IDLE) {
+                // rank of this lane among the idle ones: v_mbcnt (set bits of the mask below the lane), no lane-mask registers
+                unsigned q = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                if (q < end) {
+                    slot = queue ? queue[q] : q;
+                    float4 g0 = st.G0[slot], g1 = st.G1[slot];
+                    // both groups in ONE round trip (left alone the compiler fetches the flags word first and the rest behind the branch)
+                    asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
+                    const unsigned fl = __float_as_uint(g1.w);
+                    if (fl & FL_ALIVE) {
+                        d = v3(g0.w, g1.x, g1.y);
+                        probe = PROBES && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
+                        o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
+                        invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        ob = probe ? probeObjOf(fl) : 0;
+                        obEnd = probe ? ob + 1 : sc.numObj;
+                        closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; sp = 0; cur = CUR_NONE;
+                        for (int k = 0; k < nObjLds; k += 2) {              // two root boxes per packed-f32 test, like the two children of a node
+                            const int kb = min(k + 1, nObjLds - 1);
+                            const float4 a0 = rootsL[2 * k], a1 = rootsL[2 * k + 1], b0 = rootsL[2 * kb], b1 = rootsL[2 * kb + 1];
+                            float da, db;
+                            rayBox2(o, invD, make_float4(a0.x, b0.x, a0.y, b0.y), make_float4(a0.z, b0.z, a0.w, b0.w), make_float4(a1.x, b1.x, a1.y, b1.y), da, db);
+                            rootDist[k * TPB] = da;
+                            if (k + 1 < nObjLds) rootDist[(k + 1) * TPB] = db;
+                        }
+                    }
+                }
+            }
+            pos += (unsigned)nIdle;
+            mode = M_VOTE;
+        } else if (mode == M_NONE) {
+            // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire
+            PS(1, __popcll(__ballot(cur == CUR_NONE)));
+            if (cur == CUR_NONE) {
+                while (ob < obEnd) {
+                    float rd; int rref;
+                    if (ob < nObjLds) { rd = rootDist[ob * TPB]; rref = __float_as_int(rootsL[2 * ob + 1].z); }
+                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); rref = R.ref; }
+                    ob++;
+                    if (COUNT) c.boxtests++;
+                    if (rd > closest) continue;
+                    if (rref == REF_EMPTY) { if (COUNT) c.nodes++; continue; }
+                    cur = rref;
+                    break;
+                }
+                if (cur == CUR_NONE) {                                      // all BVHs done: ellipsoids (:606-631), then retire the ray
+                    for (int i = 0; i < (probe ? 0 : sc.numEllip); i++) {
+                        const EllipRec& E = sc.ellip[i];
+                        vec3 cc = v3(E.c[0], E.c[1], E.c[2]);
+                        float t;
+                        if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        if (t < closest) {
+                            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) {                            // see intersectScene
+                                if (st.HX) st.HX[slot] = make_float4(hu, hv, __int_as_float(prim), 0.0f);
+                                hu = __int_as_float(prim);
+                            }
+                            closest = t; prim = PRIM_ELLIPSOID | i;
+                        }
+                    }
+                    st.H[slot] = make_float4(closest, hu, hv, __int_as_float(prim));
+                    cur = CUR_IDLE;
+                }
+            }
+            mode = M_VOTE;
+        } else if (mode == M_INNER) {
+            // ---- inner-node step (:521-532); the phase repeats while most of the lanes that started it still sit on inner nodes
+            PS(2, __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE)));
+            if ((unsigned)cur < (unsigned)CUR_NONE) {
+                float4 q0, q1, q2, q3;
+                loadNode(sc, ldsN, cur, q0, q1, q2, q3);
+                if (COUNT) { c.nodes++; c.boxtests += 2; }
+                float Ld, Rd;
+                rayBox2(o, invD, q0, q1, q2, Ld, Rd);
+                const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
+                if (COUNT) { if (Ld < closest && lref == REF_EMPTY) c.nodes++; if (Rd < closest && rref == REF_EMPTY) c.nodes++; }
+                // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
+                const bool rNear = Ld > Rd;
+                const int nearRef = rNear ? rref : lref, farRef = rNear ? lref : rref;
+                const float nearD = rNear ? Rd : Ld, farD = rNear ? Ld : Rd;
+                const bool nearOk = nearD < closest && nearRef != REF_EMPTY, farOk = farD < closest && farRef != REF_EMPTY;
+                if (nearOk) {
+                    cur = nearRef;
+                    if (farOk) {
+                        stk[sp * TPB] = (ElemT)farRef; sp++;
+                        if (PACKED) { hiB = __builtin_amdgcn_alignbit(hiB, hiA, 30); hiA = (hiA << 2) | (((unsigned)farRef >> 16) & 3u); }
+                    }
+                } else if (farOk) {
+                    cur = farRef;
+                } else if (sp > 0) {
+                    cur = (int)stk[(--sp) * TPB];
+                    if (PACKED) { cur = (int)(((unsigned)cur | (hiA << 16)) << 14) >> 14; hiA = __builtin_amdgcn_alignbit(hiB, hiA, 2); hiB >>= 2; }
+                } else {
+                    cur = CUR_NONE;
+                }
+            }
+            if (__popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE)) <= thr) mode = M_VOTE;
+        } else {
+            // ---- leaf step: one triangle of the pending leaf (:483-520); repeats while most lanes still have triangles left in
+            // their leaf (the reference's builder can leave many triangles in one leaf)
+            PS(3, __popcll(__ballot(cur < 0)));
+            bool more = false;
+            if (cur < 0) {
+                int ti = -(cur + 1);
+                float4 t0, t1, t2;
+                loadTri(sc, ldsT, ti, t0, t1, t2);
+                unsigned idl = __float_as_uint(t2.y);
+                float t, u, v;
+                if (COUNT) c.tritests++;
+                rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
+                if (t > 0.0f && t < closest) {                          // :489
+                    closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
+                    if (COUNT) c.hitupd++;
+                }
+                if (idl >> 31) {                                        // last triangle of the leaf: this node is done
+                    if (COUNT) c.nodes++;
+                    if (sp > 0) {
+                        cur = (int)stk[(--sp) * TPB];
+                        if (PACKED) { cur = (int)(((unsigned)cur | (hiA << 16)) << 14) >> 14; hiA = __builtin_amdgcn_alignbit(hiB, hiA, 2); hiB >>= 2; }
+                    } else cur = CUR_NONE;
+                } else {
+                    cur = cur - 1;                                      // next triangle record of the same leaf
+                    more = true;
+                }
+            }
+            if (__popcll(__ballot(more)) <= thr) mode = M_VOTE;
+        }
+    }
+#else
     for (;;) {
         // ---- refill idle lanes from the wave's range
         unsigned long long idle = __ballot(cur == CUR_IDLE);
@@ -341,36 +491,25 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 if (q < end) {
                     slot = queue ? queue[q] : q;
                     float4 g0 = st.G0[slot], g1 = st.G1[slot];
-#ifdef PT_V_REFILL1
                     // both groups in ONE round trip (left alone the compiler fetches the flags word first and the rest behind the branch)
                     asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
-#endif
                     const unsigned fl = __float_as_uint(g1.w);
                     if (fl & FL_ALIVE) {
                         d = v3(g0.w, g1.x, g1.y);
                         probe = PROBES && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
-#ifdef PT_V_OPSEL
-                        { const vec3 o_ = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
-                          oxy = f32x2{o_.x, o_.y}; ozi = f32x2{o_.z, 1.0f / d.z}; ixy = f32x2{1.0f / d.x, 1.0f / d.y}; }
-#else
                         o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
                         invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-#endif
-                        ob = probe ? (int)((fl >> FL_PROBE_OBJ_SHIFT) & FL_PROBE_OBJ_MASK) : 0;
+                        ob = probe ? probeObjOf(fl) : 0;
                         obEnd = probe ? ob + 1 : sc.numObj;
                         closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; sp = 0; cur = CUR_NONE;
                         for (int k = 0; k < nObjLds; k += 2) {              // two root boxes per packed-f32 test, like the two children of a node
-#ifdef PT_V_ROOTS_LDS
                             const int kb = min(k + 1, nObjLds - 1);
                             const float4 a0 = rootsL[2 * k], a1 = rootsL[2 * k + 1], b0 = rootsL[2 * kb], b1 = rootsL[2 * kb + 1];
                             ObjRoot A, B;
                             A.bmin[0] = a0.x; A.bmin[1] = a0.y; A.bmin[2] = a0.z; A.bmax[0] = a0.w; A.bmax[1] = a1.x; A.bmax[2] = a1.y;
                             B.bmin[0] = b0.x; B.bmin[1] = b0.y; B.bmin[2] = b0.z; B.bmax[0] = b0.w; B.bmax[1] = b1.x; B.bmax[2] = b1.y;
-#else
-                            const ObjRoot A = sc.roots[k], B = sc.roots[min(k + 1, nObjLds - 1)];
-#endif
                             float da, db;
-                            RAYBOX2(make_float4(A.bmin[0], B.bmin[0], A.bmin[1], B.bmin[1]), make_float4(A.bmin[2], B.bmin[2], A.bmax[0], B.bmax[0]),
+                            rayBox2(o, invD, make_float4(A.bmin[0], B.bmin[0], A.bmin[1], B.bmin[1]), make_float4(A.bmin[2], B.bmin[2], A.bmax[0], B.bmax[0]),
                                     make_float4(A.bmax[1], B.bmax[1], A.bmax[2], B.bmax[2]), da, db);
                             rootDist[k * TPB] = da;
                             if (k + 1 < nObjLds) rootDist[(k + 1) * TPB] = db;
@@ -393,14 +532,8 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
             if (cur == CUR_NONE) {
                 while (ob < obEnd) {
                     float rd; int rref;
-#ifdef PT_V_ROOTS_LDS
                     if (ob < nObjLds) { rd = rootDist[ob * TPB]; rref = __float_as_int(rootsL[2 * ob + 1].z); }
-                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(RAY_O, RAY_INVD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); rref = R.ref; }
-#else
-                    if (ob < nObjLds) rd = rootDist[ob * TPB];
-                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(RAY_O, RAY_INVD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); }
-                    rref = sc.roots[ob].ref;
-#endif
+                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); rref = R.ref; }
                     ob++;
                     if (COUNT) c.boxtests++;
                     if (rd > closest) continue;
@@ -413,10 +546,13 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                         const EllipRec& E = sc.ellip[i];
                         vec3 cc = v3(E.c[0], E.c[1], E.c[2]);
                         float t;
-                        if (E.rotated) t = rayEllipsoid(vecmat(RAY_O, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
-                        else t = rayEllipsoid(RAY_O, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
+                        else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
                         if (t < closest) {
-                            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) hu = __int_as_float(prim);   // see intersectScene
+                            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) {                            // see intersectScene
+                                if (st.HX) st.HX[slot] = make_float4(hu, hv, __int_as_float(prim), 0.0f);
+                                hu = __int_as_float(prim);
+                            }
                             closest = t; prim = PRIM_ELLIPSOID | i;
                         }
                     }
@@ -437,7 +573,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                     loadNode(sc, ldsN, cur, q0, q1, q2, q3);
                     if (COUNT) { c.nodes++; c.boxtests += 2; }
                     float Ld, Rd;
-                    RAYBOX2(q0, q1, q2, Ld, Rd);
+                    rayBox2(o, invD, q0, q1, q2, Ld, Rd);
                     const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                     if (COUNT) { if (Ld < closest && lref == REF_EMPTY) c.nodes++; if (Rd < closest && rref == REF_EMPTY) c.nodes++; }
                     // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
@@ -447,11 +583,15 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                     const bool nearOk = nearD < closest && nearRef != REF_EMPTY, farOk = farD < closest && farRef != REF_EMPTY;
                     if (nearOk) {
                         cur = nearRef;
-                        if (farOk) { stk[sp * TPB] = (StackT)farRef; sp++; }
+                        if (farOk) {
+                            stk[sp * TPB] = (ElemT)farRef; sp++;
+                            if (PACKED) { hiB = __builtin_amdgcn_alignbit(hiB, hiA, 30); hiA = (hiA << 2) | (((unsigned)farRef >> 16) & 3u); }
+                        }
                     } else if (farOk) {
                         cur = farRef;
                     } else if (sp > 0) {
                         cur = (int)stk[(--sp) * TPB];
+                        if (PACKED) { cur = (int)(((unsigned)cur | (hiA << 16)) << 14) >> 14; hiA = __builtin_amdgcn_alignbit(hiB, hiA, 2); hiB >>= 2; }
                     } else {
                         cur = CUR_NONE;
                     }
@@ -473,14 +613,17 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                     unsigned idl = __float_as_uint(t2.y);
                     float t, u, v;
                     if (COUNT) c.tritests++;
-                    rayTri(RAY_O, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
+                    rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
                     if (t > 0.0f && t < closest) {                          // :489
                         closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
                         if (COUNT) c.hitupd++;
                     }
                     if (idl >> 31) {                                        // last triangle of the leaf: this node is done
                         if (COUNT) c.nodes++;
-                        cur = (sp > 0) ? (int)stk[(--sp) * TPB] : CUR_NONE;
+                        if (sp > 0) {
+                            cur = (int)stk[(--sp) * TPB];
+                            if (PACKED) { cur = (int)(((unsigned)cur | (hiA << 16)) << 14) >> 14; hiA = __builtin_amdgcn_alignbit(hiB, hiA, 2); hiB >>= 2; }
+                        } else cur = CUR_NONE;
                     } else {
                         cur = cur - 1;                                      // next triangle record of the same leaf
                         more = true;
@@ -490,6 +633,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
             } while (nMore > keepGoing);
         }
     }
+#endif
     if (COUNT) {
         atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
         atomicAdd(&ctl->cnt[PT_CNT_TRITESTS], (unsigned long long)c.tritests);
@@ -503,9 +647,6 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
     if (lane == 0 && waveId < 8192) { ctl->waveEnd[waveId] = __builtin_amdgcn_s_memrealtime(); ctl->waveStart[waveId] = tStart; }
 #endif
 #undef PS
-#undef RAY_O
-#undef RAY_INVD
-#undef RAYBOX2
 }
 
 // trace() loop body + sample/job bookkeeping for every live path slot.
@@ -567,8 +708,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         g3in = g3;
         p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
         isProbe = DIRECT && p.probe;
-        if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w));      // RAYTRACING == 0 (frag.glsl:911-912)
-        else sampleDone = shadeSegment<TRANS, TEX>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, i);
+        if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w), st.HX, i);      // RAYTRACING == 0 (frag.glsl:911-912)
+        else sampleDone = shadeSegment<TRANS, TEX>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i);
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
             p.sample++;
@@ -792,7 +933,7 @@ struct pt_ctx {
     std::vector<HostTex> textures;          // bindless table beyond the sky (index 0 mirrors `sky`)
     float4* dTexels = nullptr; TexRec* dTexTable = nullptr;      // all textures beyond the sky in one allocation + the bindless-style table
     bool sceneDirty = true, frameInDirty = true;
-    bool trans = false, anySubsurface = false, ambiguousTriObj = false, anyMaps = false; int* dTriObj = nullptr;
+    bool trans = false, anySubsurface = false, ambiguousTriObj = false, anyMaps = false, ellipMaps = false; int* dTriObj = nullptr;
     int stackDepth = 1;
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
@@ -805,7 +946,7 @@ struct pt_ctx {
     float4* dImage[IMAGES] = {nullptr, nullptr, nullptr, nullptr}; int curImage = 0;      // FRAME images (more than one only after pt_next_image)
     // path pool
     int poolSlots = 0;              // 0 = automatic: jobs/5 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
-    int poolActive = 0; int allocSlots = 0; bool allocTrans = false;
+    int poolActive = 0; int allocSlots = 0; bool allocTrans = false, allocHX = false;
     State st{};
     unsigned* dQueue[2] = {nullptr, nullptr};      // dense slot queues of the batch tail, by iteration parity
     float4* dColbuf = nullptr; int* dSeeds = nullptr; int ringFrames = 0;      // per-frame rings of the stream (Batch)
@@ -824,7 +965,9 @@ struct pt_ctx {
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
     int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
     int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
-    bool stack16 = false; int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 4; int innerKeepEighths = 6;
+    int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
+    int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 4; int innerKeepEighths = 6;
+    int bfsNodes = 0x7fffffff;      // inner-node records kept in breadth-first order (whole levels); the rest follow depth-first (buildScene)
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
 };
@@ -930,6 +1073,31 @@ int buildScene(pt_ctx* c) {
             cur.swap(nxt); d++;
         }
     }
+    // Below the top levels (the LDS tile and what every XCD's L2 keeps hot anyway) the records are laid out in depth-first order
+    // instead: a node and its left child are then neighbours, and a subtree's last levels share a few cache lines — a big tree's
+    // deep fetches are what misses L2.  Only the addresses change; which nodes a ray visits, and in which order, does not.
+    if ((size_t)c->bfsNodes < order.size()) {
+        int cut = -1; size_t upTo = 0;                          // deepest level that is still completely inside the BFS prefix
+        for (size_t k = 0; k < order.size(); k++) {
+            if (k + 1 == order.size() || depth[order[k + 1]] != depth[order[k]]) {
+                if (k + 1 <= (size_t)c->bfsNodes) { cut = depth[order[k]]; upTo = k + 1; } else break;
+            }
+        }
+        std::vector<int> reordered(order.begin(), order.begin() + upTo), stack;
+        for (size_t k = upTo; k < order.size() && depth[order[k]] == cut + 1; k++) {
+            stack.assign(1, order[k]);
+            while (!stack.empty()) {
+                int n = stack.back(); stack.pop_back();
+                reordered.push_back(n);
+                int L = childOf(n, 0), R = childOf(n, 1);
+                if (!isLeaf(R)) stack.push_back(R);
+                if (!isLeaf(L)) stack.push_back(L);
+            }
+        }
+        if (reordered.size() != order.size()) return fail(PT_ERR_SCENE, "internal: depth-first relayout lost nodes");
+        order.swap(reordered);
+        for (size_t k = 0; k < order.size(); k++) newIdx[order[k]] = (int)k;
+    }
     int need = maxInnerDepth + 2;                               // worst-case entries on rayBVH's stack
     if (need > 64) return fail(PT_ERR_SCENE, "BVH too deep for the reference's `int stack[64]` (frag.glsl:465)");
     c->stackDepth = std::max(need, 1);
@@ -982,14 +1150,16 @@ int buildScene(pt_ctx* c) {
     int nE = (int)c->ellip[0];
     if (nE < 0 || c->ellip.size() < (size_t)1 + 11 * (size_t)nE) return fail(PT_ERR_SCENE, "EllipData shorter than its count says");
     std::vector<EllipRec> er(std::max(nE, 1));
+    bool ellipMaps = false;
     for (int i = 0; i < nE; i++) {
         const float* E = c->ellip.data();
         EllipRec& r = er[i]; std::memset(&r, 0, sizeof(r));
         for (int k = 0; k < 3; k++) { r.c[k] = E[1 + 3 * i + k]; r.st[k] = E[1 + nE * 3 + 3 * i + k]; r.rot[k] = E[1 + nE * 6 + 3 * i + k]; }
         r.r = E[1 + nE * 9 + i]; r.mat = (int)E[1 + nE * 10 + i];
         if (r.mat < 0 || r.mat >= nMat) return fail(PT_ERR_SCENE, "ellipsoid material index out of range");
-        if (mats[r.mat].hasMaps) return fail(PT_ERR_UNSUPPORTED, "ellipsoids with texture-mapped materials: the shader samples them at the uv of the closest triangle behind them (hitUV is not reset, frag.glsl:574 vs :619-630) - not restated on the device");
+        if (mats[r.mat].hasMaps) ellipMaps = true;               // sampled at the uv of the closest triangle found before the ellipsoid (frag.glsl:574 vs :619-630): State::HX
     }
+    c->ellipMaps = ellipMaps;
     // upload
     hipStream_t s = c->stream;
     HIP_TRY(hipStreamSynchronize(s));
@@ -1037,7 +1207,8 @@ int buildScene(pt_ctx* c) {
     }
     sc.ldsNodes = ln; sc.ldsTris = lt;
     // persistent kernel: one staged tile per resident block
-    c->stack16 = sc.nNodes < 32767 && sc.nTriRecs < 32767;
+    c->stackMode = (sc.nNodes < 32767 && sc.nTriRecs < 32767) ? 0 : (sc.nNodes <= 131071 && sc.nTriRecs <= 131071 && c->stackDepth <= 32) ? 1 : 2;
+    if (c->stackModeForce >= 0) c->stackMode = std::max(c->stackMode, c->stackModeForce);      // only ever towards wider entries
     {
         int cb = c->extendCacheBytes;
         int pn = std::min(sc.nNodes, cb / 64);
@@ -1050,21 +1221,21 @@ int buildScene(pt_ctx* c) {
 
 int ensurePool(pt_ctx* c, int capacity) {               // capacity >= poolActive: room for a pool that grows while a stream runs
     capacity = std::max(capacity, c->poolActive);
-    if (c->allocSlots >= capacity && c->allocTrans == c->trans) return 0;
+    if (c->allocSlots >= capacity && c->allocTrans == c->trans && c->allocHX == c->ellipMaps) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->allocSlots = 0;                                            // until every allocation below has succeeded there is no pool
-    float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H};
+    float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H, &c->st.HX};
     for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
     for (unsigned** q : {&c->dQueue[0], &c->dQueue[1]}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     size_t n = (size_t)capacity;
-    for (int k = 0; k < 10; k++) {
+    for (int k = 0; k < 11; k++) {
         bool transOnly = (k >= 5 && k <= 8);
-        if (transOnly && !c->trans) continue;
+        if ((transOnly && !c->trans) || (k == 10 && !c->ellipMaps)) continue;
         HIP_TRY(hipMalloc((void**)groups[k], n * 16));
     }
     HIP_TRY(hipMalloc((void**)&c->dQueue[0], n * 4));
     HIP_TRY(hipMalloc((void**)&c->dQueue[1], n * 4));
-    c->allocSlots = capacity; c->allocTrans = c->trans;
+    c->allocSlots = capacity; c->allocTrans = c->trans; c->allocHX = c->ellipMaps;
     return 0;
 }
 
@@ -1104,7 +1275,7 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     DevScene sc = c->sc;
     int tpb = c->extendTpb;
     // LDS per block: [node tile][triangle tile][root-box distances][traversal stacks]; the tile takes what the fixed parts leave
-    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stack16 ? 2 : 4) + 64 + 32 * 8;     // + the LDS copies of up to 8 object roots
+    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stackMode == 2 ? 4 : 2) + 64 + 32 * 8;     // + the LDS copies of up to 8 object roots
     size_t avail = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
     size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, avail);
     {   // a smaller node tile (down to 6 KB) if that lets one more block — two more waves per SIMD — live on the CU: occupancy is worth
@@ -1128,8 +1299,8 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     grid = std::max(1, std::min(grid, maxUseful));
 #define EP(COUNT, T, TPB) launchEP<COUNT, T, TPB>(c, pr, sc, lds, grid)
 #define EP_T(COUNT, T) do { if (tpb == 256) EP(COUNT, T, 256); else if (tpb == 512) EP(COUNT, T, 512); else EP(COUNT, T, 1024); } while (0)
-    if (c->countStats) { if (c->stack16) EP_T(true, short); else EP_T(true, int); }
-    else { if (c->stack16) EP_T(false, short); else EP_T(false, int); }
+    if (c->countStats) { if (c->stackMode == 0) EP_T(true, short); else if (c->stackMode == 1) EP_T(true, Packed18); else EP_T(true, int); }
+    else { if (c->stackMode == 0) EP_T(false, short); else if (c->stackMode == 1) EP_T(false, Packed18); else EP_T(false, int); }
 #undef EP
 #undef EP_T
 }
@@ -1292,8 +1463,9 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         return 0;
     }
     if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
-    if (!(P[4] >= 1.0f) || P[4] > 255.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,255]");
-    if (!(P[5] > 0.0f) || P[5] > 255.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,255]");
+    // the loop bounds are floats in the shader (frag.glsl:820, :898); the slot's counters have 12 bits each
+    if (!(P[4] >= 1.0f) || P[4] > 4095.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,4095]");
+    if (!(P[5] > 0.0f) || P[5] > 4095.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,4095]");
     size_t nJobs64 = (size_t)c->nLocal * (size_t)nFrames;
     if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
     FrameIn fin;
@@ -1312,7 +1484,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     if (!join) {                                                  // ---- a new stream
         if (c->sceneDirty && (rc = buildScene(c))) return rc;
         if (direct && c->anySubsurface) {
-            if (c->sc.numObj > (int)FL_PROBE_OBJ_MASK) return fail(PT_ERR_UNSUPPORTED, "directDiffuse with subsurface materials supports at most 127 objects (BVHs)");
+            if (c->sc.numObj > FL_PROBE_OBJ_MAX + 1) return fail(PT_ERR_UNSUPPORTED, "directDiffuse with subsurface materials supports at most 65536 objects (BVHs)");
             if (c->ambiguousTriObj) return fail(PT_ERR_SCENE, "directDiffuse with subsurface materials needs every triangle to belong to one BVH (hit.parentID, frag.glsl:573)");
         }
         if (c->poolSlots > 0) c->poolActive = c->poolSlots;
@@ -1491,7 +1663,7 @@ int pt_destroy(pt_ctx* c) {
     flushStream(c);
     hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
-                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
+                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hCtl) hipHostFree(c->hCtl);
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
@@ -1732,6 +1904,8 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
         case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
+        case 11: if (value < -1 || value > 2) return fail(PT_ERR_ARG, "stack mode must be -1 (automatic), 0, 1 or 2"); c->stackModeForce = (int)value; c->sceneDirty = true; return PT_OK;
+        case 10: if (value < 0 || value > 0x7fffffff) return fail(PT_ERR_ARG, "breadth-first node count out of range"); c->bfsNodes = (int)value; c->sceneDirty = true; return PT_OK;
     }
     return fail(PT_ERR_ARG, "unknown option");
 }

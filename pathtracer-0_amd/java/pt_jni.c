@@ -25,6 +25,15 @@ JNIEXPORT jlong JNICALL Java_Main_PtNative_create(JNIEnv* env, jclass c, jint de
     if (pt_create(&ctx, device, w, h, rank, count) != PT_OK) { throw_rt(env, "pt_create"); return 0; }
     return (jlong)(intptr_t)ctx;
 }
+JNIEXPORT jlong JNICALL Java_Main_PtNative_createMulti(JNIEnv* env, jclass c, jintArray devices, jint w, jint h) {
+    pt_ctx* ctx = NULL;
+    jsize n = (*env)->GetArrayLength(env, devices);
+    jint* d = (*env)->GetIntArrayElements(env, devices, NULL);
+    int rc = pt_create_multi(&ctx, (const int*)d, (int)n, w, h);
+    (*env)->ReleaseIntArrayElements(env, devices, d, JNI_ABORT);
+    if (rc != PT_OK) { throw_rt(env, "pt_create_multi"); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
 JNIEXPORT void JNICALL Java_Main_PtNative_destroy(JNIEnv* env, jclass c, jlong h) { pt_destroy(CTX(h)); }
 JNIEXPORT void JNICALL Java_Main_PtNative_setBuffer(JNIEnv* env, jclass c, jlong h, jint binding, jobject buf, jlong bytes) {
     void* p = (*env)->GetDirectBufferAddress(env, buf);
@@ -43,6 +52,36 @@ JNIEXPORT void JNICALL Java_Main_PtNative_renderBatch(JNIEnv* env, jclass c, jlo
     (*env)->ReleaseIntArrayElements(env, seeds, s, JNI_ABORT);
     if (rc != PT_OK) throw_rt(env, "pt_render_batch");
 }
+JNIEXPORT void JNICALL Java_Main_PtNative_renderBatchAsync(JNIEnv* env, jclass c, jlong h, jint first, jintArray seeds) {
+    jsize n = (*env)->GetArrayLength(env, seeds);
+    jint* s = (*env)->GetIntArrayElements(env, seeds, NULL);
+    int rc = pt_render_batch_async(CTX(h), first, (int)n, (const int32_t*)s);
+    (*env)->ReleaseIntArrayElements(env, seeds, s, JNI_ABORT);
+    if (rc != PT_OK) throw_rt(env, "pt_render_batch_async");
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_nextImage(JNIEnv* env, jclass c, jlong h) { CHECK(pt_next_image(CTX(h)), "pt_next_image"); }
+JNIEXPORT void JNICALL Java_Main_PtNative_finishImage(JNIEnv* env, jclass c, jlong h, jint age) { CHECK(pt_finish_image(CTX(h), age), "pt_finish_image"); }
+JNIEXPORT jlong JNICALL Java_Main_PtNative_imageDevice(JNIEnv* env, jclass c, jlong h, jint age, jlongArray slots) {
+    void* p = NULL; size_t n = 0;
+    if (pt_image_device(CTX(h), age, &p, &n) != PT_OK) { throw_rt(env, "pt_image_device"); return 0; }
+    if (slots && (*env)->GetArrayLength(env, slots) > 0) { jlong v = (jlong)n; (*env)->SetLongArrayRegion(env, slots, 0, 1, &v); }
+    return (jlong)(intptr_t)p;
+}
+JNIEXPORT jlong JNICALL Java_Main_PtNative_gatherImage(JNIEnv* env, jclass c, jlong h, jint age) {
+    void* p = NULL;
+    if (pt_gather_image(CTX(h), age, &p) != PT_OK) { throw_rt(env, "pt_gather_image"); return 0; }
+    return (jlong)(intptr_t)p;
+}
+JNIEXPORT jlongArray JNICALL Java_Main_PtNative_getCounters(JNIEnv* env, jclass c, jlong h) {
+    uint64_t cnt[PT_CNT_N];
+    if (pt_get_counters(CTX(h), cnt, PT_CNT_N) != PT_OK) { throw_rt(env, "pt_get_counters"); return NULL; }
+    jlong v[PT_CNT_N];
+    for (int k = 0; k < PT_CNT_N; k++) v[k] = (jlong)cnt[k];
+    jlongArray out = (*env)->NewLongArray(env, PT_CNT_N);
+    if (out) (*env)->SetLongArrayRegion(env, out, 0, PT_CNT_N, v);
+    return out;
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_resetCounters(JNIEnv* env, jclass c, jlong h) { CHECK(pt_reset_counters(CTX(h)), "pt_reset_counters"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_renderAsync(JNIEnv* env, jclass c, jlong h, jint frameCount, jint seed) {
     int32_t s = (int32_t)seed;
     CHECK(pt_render_batch_async(CTX(h), frameCount, 1, &s), "pt_render_batch_async");

@@ -129,3 +129,29 @@ def test_gather_layout_roundtrip(pt):
         out = np.zeros_like(full)
         out[maps[maps >= 0]] = gathered[maps >= 0]
         assert np.array_equal(out, full)
+
+
+def test_jni_shim_covers_the_boundary():
+    """pathtracer-0_amd/java: every native method of Main.PtNative has its JNI function in pt_jni.c, every C-ABI call the shim makes is
+    declared in include/pt_api.h, and the shim reaches every entry point a Java host needs (no JDK here: a text-level consistency check)"""
+    java = open(os.path.join(ROOT, "pathtracer-0_amd", "java", "Main", "PtNative.java")).read()
+    jni = open(os.path.join(ROOT, "pathtracer-0_amd", "java", "pt_jni.c")).read()
+    natives = re.findall(r"public static native [\w\[\]]+ (\w+)\(", java)
+    assert len(natives) >= 19
+    for n in natives:
+        assert f"Java_Main_PtNative_{n}(" in jni, n
+    assert len(re.findall(r"JNIEXPORT", jni)) == len(natives)
+    api = set(declared("pt_api.h"))
+    called = set(re.findall(r"\b(pt_[a-z_]+)\(", jni))
+    assert called <= api, called - api
+    for need in ("pt_create", "pt_create_multi", "pt_destroy", "pt_set_buffer", "pt_set_texture", "pt_reset_frame", "pt_render", "pt_render_batch", "pt_render_batch_async",
+                 "pt_next_image", "pt_finish_image", "pt_image_device", "pt_gather_image", "pt_synchronize", "pt_read_frame", "pt_read_display", "pt_get_counters",
+                 "pt_reset_counters", "pt_last_error"):
+        assert need in called, need
+
+
+def test_c_client_names_every_boundary_symbol():
+    """tests/c/abi_client.c drives every entry point of include/pt_api.h (the GPU test runs it; this one keeps the list complete)"""
+    src = open(os.path.join(ROOT, "tests", "c", "abi_client.c")).read()
+    for n in declared("pt_api.h"):
+        assert f"SYM(hip, {n})" in src, n

@@ -96,6 +96,70 @@ def test_intersect_parity(pt, oracle, renderer_mod, name, W, H):
             assert prim[i] == exp and tuv[i, 0] == out[0], (i, prim[i], exp, tuv[i, 0], out[0])
 
 
+def _raybox_np(o, invd, mn, mx, ieee):
+    """rayBox (frag.glsl:408-419) on arrays, with IEEE minNum/maxNum (what v_min_f32 / v_max_f32 and every GPU's GLSL min/max do) or
+    with the GLSL specification's min(x,y) = (y < x) ? y : x, max(x,y) = (x < y) ? y : x"""
+    with np.errstate(all="ignore"):
+        tmin = ((mn - o) * invd).astype(np.float32); tmax = ((mx - o) * invd).astype(np.float32)
+        if ieee:
+            mn2, mx2 = np.fmin, np.fmax
+        else:
+            mn2 = lambda x, y: np.where(y < x, y, x)          # noqa: E731
+            mx2 = lambda x, y: np.where(x < y, y, x)          # noqa: E731
+        t1, t2 = mn2(tmin, tmax), mx2(tmin, tmax)
+        tnear = mx2(mx2(t1[..., 0], t1[..., 1]), t1[..., 2]); tfar = mn2(mn2(t2[..., 0], t2[..., 1]), t2[..., 2])
+        return np.where((tfar >= tnear) & (tfar > 0), np.where(tnear > 0, tnear, 0), np.float32(1e30))
+
+
+def test_nan_slab_rays(pt, oracle, renderer_mod):
+    """rayBox with a 0 * inf slab (frag.glsl:409-417): a ray that starts exactly ON a box plane and runs exactly parallel to it.  The two
+    readings of min/max differ only when BOTH slab distances are NaN — a flat box (an axis-aligned wall) with the ray in its plane: minNum
+    ignores the slab, the specification's formula misses the box.  Both sides of the parity pair use minNum; this test
+    runs such rays through both, and checks that the set really contains boxes on which the two readings differ."""
+    wl = pt.scenes.build("C2", 96, 54)
+    boxes = np.array(wl.buffers[10], np.float32).reshape(-1, 8)
+    mn, mx = boxes[:, 0:3], boxes[:, 3:6]
+    O, D = [], []
+    for k in range(len(boxes)):
+        c = (mn[k] + mx[k]) * np.float32(0.5)
+        for a in range(3):
+            for plane in (mn[k, a], mx[k, a]):
+                for b in range(3):
+                    if b == a:
+                        continue
+                    for sgn in (1.0, -1.0):
+                        o = c.copy(); o[a] = plane; o[b] -= np.float32(sgn * 3.0)
+                        d = np.zeros(3, np.float32); d[b] = sgn
+                        d[a] = 0.0 if sgn > 0 else -0.0                      # 1/d = +inf and -inf
+                        O.append(o); D.append(d)
+    O, D = np.array(O, np.float32), np.array(D, np.float32)
+    with np.errstate(all="ignore"):
+        invd = (np.float32(1.0) / D).astype(np.float32)
+    a_ieee = _raybox_np(O[:, None, :], invd[:, None, :], mn[None], mx[None], True)
+    a_spec = _raybox_np(O[:, None, :], invd[:, None, :], mn[None], mx[None], False)
+    assert (a_ieee != a_spec).sum() > 100, "the ray set must contain boxes on which minNum and the specification's min/max differ"
+    r = renderer_mod.Renderer(96, 54)
+    r.load_workload(wl)
+    tuv, prim = r.debug_intersect(O, D)
+    r.close()
+    sc = oracle.Scene.from_workload(wl)
+    hits = 0
+    for i in range(len(O)):
+        code, out = oracle.ray_scene(sc, O[i], D[i])
+        if code < 0:
+            assert prim[i] == -1 or not (tuv[i, 0] < 1e25), (i, prim[i], tuv[i])
+        else:
+            hits += 1
+            assert prim[i] == (code & 0xFFFFFF) and tuv[i, 0] == out[0], (i, prim[i], code, tuv[i, 0], out[0])
+    assert hits > 50
+    # and through the whole path with traversal counters: a camera whose primary rays are axis-parallel in one component
+    wl2 = wl.with_params(BLUR=0.0, AUTO_FOCUS=0)
+    b = dict(wl2.buffers); b[0] = np.array([0.0, float(mx[0, 1]), -3.0], np.float32); b[1] = np.zeros(3, np.float32)
+    wl2 = pt.scenes.Workload("C2_grazing", wl2.W, wl2.H, b, wl2.sky, wl2.sample_res, wl2.max_bounces, wl2.info)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl2, 2)
+    assert_same(got, ref, cnt, ocnt)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("name,W,H,frames", [("C1", 64, 64, 2), ("C2", 96, 54, 3), ("C3", 96, 54, 3), ("C5", 64, 36, 2)])
 def test_render_parity_small(pt, oracle, renderer_mod, name, W, H, frames, mode):
@@ -109,6 +173,15 @@ def test_render_parity_persistent_variants(pt, oracle, renderer_mod, tpb, cache,
     """persistent intersect kernel: block size, LDS tile size (partial / whole BVH) and refill threshold do not change results"""
     wl = pt.scenes.build("C3", 128, 72)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, extend_mode=1, extend_tpb=tpb, extend_cache_bytes=cache, refill_min=refill)
+    assert_same(got, ref, cnt, ocnt)
+
+
+@pytest.mark.parametrize("name,W,H,stack_mode,bfs_nodes", [("C3", 96, 54, 1, 0), ("C3", 96, 54, 2, 15), ("C4", 64, 36, -1, 1000), ("C4", 64, 36, 2, 100000), ("C5", 64, 36, 1, 3)])
+def test_render_parity_stack_widths_and_node_layouts(pt, oracle, renderer_mod, name, W, H, stack_mode, bfs_nodes):
+    """the three widths of the traversal-stack entries (16-bit, 16 + 2 register bits, 32-bit) and the breadth-first / depth-first record
+    layouts are pure re-encodings: same bits, same traversal counters (C4's 100 k-triangle tree takes the 18-bit form by itself)"""
+    wl = pt.scenes.build(name, W, H)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, stack_mode=stack_mode, bfs_nodes=bfs_nodes)
     assert_same(got, ref, cnt, ocnt)
 
 
@@ -401,6 +474,7 @@ def test_big_leaves_and_empty_leaf(pt, oracle, renderer_mod):
 
 
 @pytest.mark.parametrize("kw", [dict(SAMPLE_RES=1, MAX_BOUNCES=1), dict(SAMPLE_RES=3, MAX_BOUNCES=2.5), dict(AUTO_FOCUS=0, FOCAL_DISTANCE=2.5, BLUR=0.05),
+                                dict(SAMPLE_RES=300, MAX_BOUNCES=2), dict(SAMPLE_RES=2, MAX_BOUNCES=700.5),
                                 dict(BLUR=0.0), dict(screenSize=0.7, focalLength=1.3)])
 def test_parameter_block_variants(pt, oracle, renderer_mod, kw):
     """Parameters block (frag.glsl:39-52): float loop bounds (:820,:898), auto-focus off, lens blur, field of view"""
@@ -547,7 +621,7 @@ def test_gpu_bvh_builder_errors(pt):
         sc.addObjectText("o one\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n", 0)
 
 
-def test_n3_missing_texture_and_mapped_ellipsoid_are_errors(pt, renderer_mod):
+def test_n3_missing_texture_is_an_error(pt, renderer_mod):
     wl = pt.scenes.build("T1", 64, 36)
     r = renderer_mod.Renderer(64, 36)
     for bnd, arr in wl.buffers.items():
@@ -557,21 +631,29 @@ def test_n3_missing_texture_and_mapped_ellipsoid_are_errors(pt, renderer_mod):
         r.render(1, 1)
     assert e.value.code == -4
     r.close()
-    wl1 = pt.scenes.build("C1", 64, 64)
-    b = dict(wl1.buffers); m = b[14].copy(); m[23] = 0.0   # material 0 (also on an ellipsoid): map_Kd = texture 0
+
+
+@pytest.mark.parametrize("raytracing,mode", [(1, 1), (1, 0), (0, 1)])
+def test_n3_mapped_material_on_ellipsoids(pt, oracle, renderer_mod, raytracing, mode):
+    """a texture-mapped material on an ellipsoid is sampled at the uv of the closest TRIANGLE the BVH loop found before it (hitUV is
+    written at frag.glsl:574 only, not at :619-630), (0,0) when no triangle lies on the ray: C1's spheres over its ground quad"""
+    wl1 = pt.scenes.build("C1", 96, 96)
+    b = dict(wl1.buffers); m = b[14].copy()
+    m[23] = 1.0                                   # material 0 (ground AND an ellipsoid): map_Kd = texture 1
+    m[48 + 33] = 2.0                              # material 1 (ellipsoids only): map_Pr = texture 2
     b[14] = m
-    r = renderer_mod.Renderer(64, 64)
-    for bnd, arr in b.items():
-        r.set_buffer(bnd, arr)
-    r.set_texture(0, wl1.sky)
-    with pytest.raises(renderer_mod.PtError) as e:
-        r.render(1, 1)
-    assert e.value.code == -5
-    r.close()
+    rs = np.random.RandomState(4)
+    tex = {1: rs.randint(0, 256, size=(5, 7, 4)).astype(np.uint8), 2: rs.randint(0, 256, size=(3, 2, 4)).astype(np.uint8)}
+    wl = pt.scenes.Workload(wl1.name + "_mapped", wl1.W, wl1.H, b, wl1.sky, wl1.sample_res, wl1.max_bounces, dict(wl1.info), tex)
+    wl = wl.with_params(RAYTRACING=raytracing)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, extend_mode=mode)
+    assert_same(got, ref, cnt, ocnt)
+    plain, _, _, _ = render_both(pt, oracle, renderer_mod, wl1.with_params(RAYTRACING=raytracing), 3, extend_mode=mode)
+    assert not np.array_equal(got, plain)         # the maps do change the picture
 
 
 # ---- randomized scenes: every material lobe, texture maps, ellipsoids (stretched, rotated), several objects, odd cameras — in combination
-def _random_workload(pt, seed, W=72, H=44):
+def _random_workload(pt, seed, W=72, H=44, ellipsoid_maps=False):
     rs = np.random.RandomState(seed)
     sc = pt.hostlib.Scene()
     names = []
@@ -596,7 +678,7 @@ def _random_workload(pt, seed, W=72, H=44):
         elif kind == 4:
             sc.setLastMtl("subsurface", float(rs.uniform(0.2, 0.9))); sc.setLastMtl("subsurfaceColor", rs.uniform(0.1, 1, 3)); sc.setLastMtl("subsurfaceRadius", rs.uniform(0.1, 1, 3))
             sc.setLastMtl("Ka", rs.uniform(0, 0.2, 3))
-        if m >= 2 and rs.rand() < 0.5:                              # maps on some triangle-only materials (never on the ellipsoids' 0 and 1)
+        if (m >= 2 or ellipsoid_maps) and rs.rand() < 0.5:          # maps on triangle-only materials; with ellipsoid_maps also on the ellipsoids' 0 and 1
             for field in rs.choice(["map_Kd", "map_Ks", "map_Ke", "map_Pr", "map_Pm", "map_Pc", "map_Tr", "map_Ka", "map_bump"], size=rs.randint(1, 4), replace=False):
                 t = len(textures) + 1
                 textures[t] = rs.randint(0, 256, size=(rs.randint(1, 9), rs.randint(1, 9), 4)).astype(np.uint8)
@@ -633,9 +715,9 @@ def _random_workload(pt, seed, W=72, H=44):
     return wl
 
 
-@pytest.mark.parametrize("seed", list(range(1, 13)))
+@pytest.mark.parametrize("seed", list(range(1, 19)))
 def test_random_scenes(pt, oracle, renderer_mod, seed):
-    wl = _random_workload(pt, seed)
+    wl = _random_workload(pt, seed, ellipsoid_maps=seed > 12)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
     assert_same(got, ref, cnt, ocnt)
     direct = wl.with_params(RAYTRACING=0)
