@@ -281,7 +281,7 @@ template <> struct StackElem<Packed18> { typedef unsigned short type; };
 #ifndef PT_EP_WAVES
 #define PT_EP_WAVES 8        // waves per SIMD the register allocation must leave room for (4 blocks of 512 threads per CU)
 #endif
-template <bool COUNT, typename StackT, int TPB, bool PROBES>
+template <bool COUNT, typename StackT, int TPB, bool RARE>
 __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
                                                        Control* ctl, int refillMin, int keepEighths, int nObjLds, int noneMin) {
     extern __shared__ float4 smem[];
@@ -295,7 +295,9 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
     float* rootDist = reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + threadIdx.x;
     // the first nObjLds object roots (box + reference, 32 B each) are read by every refill and every next-object step: LDS copies
     float4* rootsL = reinterpret_cast<float4*>(reinterpret_cast<float*>(smem + 4 * sc.ldsNodes + 3 * sc.ldsTris) + nObjLds * TPB);
-    ElemT* stk = reinterpret_cast<ElemT*>(rootsL + 2 * nObjLds) + threadIdx.x;
+    // the slot a lane's ray came from is needed again only when the ray retires: parked in LDS, not in a register
+    unsigned* slotL = reinterpret_cast<unsigned*>(rootsL + 2 * nObjLds) + threadIdx.x;
+    ElemT* stk = reinterpret_cast<ElemT*>(reinterpret_cast<unsigned*>(rootsL + 2 * nObjLds) + TPB) + threadIdx.x;
     for (int k = threadIdx.x; k < 2 * nObjLds; k += TPB) rootsL[k] = reinterpret_cast<const float4*>(sc.roots)[k];
     for (int k = threadIdx.x; k < 4 * sc.ldsNodes; k += TPB) ldsN[k] = sc.nodes[k];
     for (int k = threadIdx.x; k < 3 * sc.ldsTris; k += TPB) ldsT[k] = sc.tris[k];
@@ -323,161 +325,6 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 #else
 #define PS(k, lanes) do { } while (0)
 #endif
-#ifdef PT_V_FLAT
-    // ONE loop whose trip runs ONE phase, named by the wave-uniform `mode`: every per-lane variable is carried around a single back
-    // edge (nested phase loops made the compiler move cur / sp / ob / closest / hu / hv / prim between register sets at every loop
-    // boundary: about a fifth of the kernel's vector instructions were such copies).
-    enum { M_VOTE = 0, M_REFILL, M_NONE, M_INNER, M_LEAF };
-    int mode = M_VOTE, thr = 0, nIdle = 0;
-    unsigned long long idle = 0;
-    for (;;) {
-        if (mode == M_VOTE) {
-            idle = __ballot(cur == CUR_IDLE);
-            nIdle = __popcll(idle);
-            PS(4, 64 - nIdle);
-            if (pos < end && nIdle >= refillMin) mode = M_REFILL;          // idle lanes take the next rays of the wave's range
-            else {
-                if (nIdle == 64) break;                                      // the range is used up and every ray has retired
-                const int nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
-                const int nLeaf = __popcll(__ballot(cur < 0));
-                const int nNone = 64 - nIdle - nInner - nLeaf;
-                // the next-object / retire step is worth a trip for noneMin lanes, or when it is the most wanted of the three
-                if (nNone >= noneMin || (nNone > 0 && nNone >= nInner && nNone >= nLeaf)) mode = M_NONE;
-                else if (nInner >= nLeaf) { mode = M_INNER; thr = (nInner * keepEighths) >> 3; }
-                else { mode = M_LEAF; thr = (nLeaf * keepEighths) >> 3; }
-            }
-        }
-        if (mode == M_REFILL) {
-            PS(0, min(nIdle, (int)(end - pos)));
-            if (cur == CUR_IDLE) {
-                // rank of this lane among the idle ones: v_mbcnt (set bits of the mask below the lane), no lane-mask registers
-                unsigned q = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                if (q < end) {
-                    slot = queue ? queue[q] : q;
-                    float4 g0 = st.G0[slot], g1 = st.G1[slot];
-                    // both groups in ONE round trip (left alone the compiler fetches the flags word first and the rest behind the branch)
-                    asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
-                    const unsigned fl = __float_as_uint(g1.w);
-                    if (fl & FL_ALIVE) {
-                        d = v3(g0.w, g1.x, g1.y);
-                        probe = PROBES && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
-                        o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
-                        invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        ob = probe ? probeObjOf(fl) : 0;
-                        obEnd = probe ? ob + 1 : sc.numObj;
-                        closest = 1e30f; hu = 0.0f; hv = 0.0f; prim = PRIM_NONE; sp = 0; cur = CUR_NONE;
-                        for (int k = 0; k < nObjLds; k += 2) {              // two root boxes per packed-f32 test, like the two children of a node
-                            const int kb = min(k + 1, nObjLds - 1);
-                            const float4 a0 = rootsL[2 * k], a1 = rootsL[2 * k + 1], b0 = rootsL[2 * kb], b1 = rootsL[2 * kb + 1];
-                            float da, db;
-                            rayBox2(o, invD, make_float4(a0.x, b0.x, a0.y, b0.y), make_float4(a0.z, b0.z, a0.w, b0.w), make_float4(a1.x, b1.x, a1.y, b1.y), da, db);
-                            rootDist[k * TPB] = da;
-                            if (k + 1 < nObjLds) rootDist[(k + 1) * TPB] = db;
-                        }
-                    }
-                }
-            }
-            pos += (unsigned)nIdle;
-            mode = M_VOTE;
-        } else if (mode == M_NONE) {
-            // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire
-            PS(1, __popcll(__ballot(cur == CUR_NONE)));
-            if (cur == CUR_NONE) {
-                while (ob < obEnd) {
-                    float rd; int rref;
-                    if (ob < nObjLds) { rd = rootDist[ob * TPB]; rref = __float_as_int(rootsL[2 * ob + 1].z); }
-                    else { const ObjRoot R = sc.roots[ob]; rd = rayBox(o, invD, R.bmin[0], R.bmin[1], R.bmin[2], R.bmax[0], R.bmax[1], R.bmax[2]); rref = R.ref; }
-                    ob++;
-                    if (COUNT) c.boxtests++;
-                    if (rd > closest) continue;
-                    if (rref == REF_EMPTY) { if (COUNT) c.nodes++; continue; }
-                    cur = rref;
-                    break;
-                }
-                if (cur == CUR_NONE) {                                      // all BVHs done: ellipsoids (:606-631), then retire the ray
-                    for (int i = 0; i < (probe ? 0 : sc.numEllip); i++) {
-                        const EllipRec& E = sc.ellip[i];
-                        vec3 cc = v3(E.c[0], E.c[1], E.c[2]);
-                        float t;
-                        if (E.rotated) t = rayEllipsoid(vecmat(o, E.R), vecmat(d, E.R), cc, E.r, E.st[0], E.st[1], E.st[2]);
-                        else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
-                        if (t < closest) {
-                            if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) {                            // see intersectScene
-                                if (st.HX) st.HX[slot] = make_float4(hu, hv, __int_as_float(prim), 0.0f);
-                                hu = __int_as_float(prim);
-                            }
-                            closest = t; prim = PRIM_ELLIPSOID | i;
-                        }
-                    }
-                    st.H[slot] = make_float4(closest, hu, hv, __int_as_float(prim));
-                    cur = CUR_IDLE;
-                }
-            }
-            mode = M_VOTE;
-        } else if (mode == M_INNER) {
-            // ---- inner-node step (:521-532); the phase repeats while most of the lanes that started it still sit on inner nodes
-            PS(2, __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE)));
-            if ((unsigned)cur < (unsigned)CUR_NONE) {
-                float4 q0, q1, q2, q3;
-                loadNode(sc, ldsN, cur, q0, q1, q2, q3);
-                if (COUNT) { c.nodes++; c.boxtests += 2; }
-                float Ld, Rd;
-                rayBox2(o, invD, q0, q1, q2, Ld, Rd);
-                const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
-                if (COUNT) { if (Ld < closest && lref == REF_EMPTY) c.nodes++; if (Rd < closest && rref == REF_EMPTY) c.nodes++; }
-                // :525-531 pushes the farther child first, so the nearer one (ties: the left one) is popped next
-                const bool rNear = Ld > Rd;
-                const int nearRef = rNear ? rref : lref, farRef = rNear ? lref : rref;
-                const float nearD = rNear ? Rd : Ld, farD = rNear ? Ld : Rd;
-                const bool nearOk = nearD < closest && nearRef != REF_EMPTY, farOk = farD < closest && farRef != REF_EMPTY;
-                if (nearOk) {
-                    cur = nearRef;
-                    if (farOk) {
-                        stk[sp * TPB] = (ElemT)farRef; sp++;
-                        if (PACKED) { hiB = __builtin_amdgcn_alignbit(hiB, hiA, 30); hiA = (hiA << 2) | (((unsigned)farRef >> 16) & 3u); }
-                    }
-                } else if (farOk) {
-                    cur = farRef;
-                } else if (sp > 0) {
-                    cur = (int)stk[(--sp) * TPB];
-                    if (PACKED) { cur = (int)(((unsigned)cur | (hiA << 16)) << 14) >> 14; hiA = __builtin_amdgcn_alignbit(hiB, hiA, 2); hiB >>= 2; }
-                } else {
-                    cur = CUR_NONE;
-                }
-            }
-            if (__popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE)) <= thr) mode = M_VOTE;
-        } else {
-            // ---- leaf step: one triangle of the pending leaf (:483-520); repeats while most lanes still have triangles left in
-            // their leaf (the reference's builder can leave many triangles in one leaf)
-            PS(3, __popcll(__ballot(cur < 0)));
-            bool more = false;
-            if (cur < 0) {
-                int ti = -(cur + 1);
-                float4 t0, t1, t2;
-                loadTri(sc, ldsT, ti, t0, t1, t2);
-                unsigned idl = __float_as_uint(t2.y);
-                float t, u, v;
-                if (COUNT) c.tritests++;
-                rayTri(o, d, v3(t0.x, t0.y, t0.z), v3(t0.w, t1.x, t1.y), v3(t1.z, t1.w, t2.x), t, u, v);
-                if (t > 0.0f && t < closest) {                          // :489
-                    closest = t; hu = u; hv = v; prim = (int)(idl & 0x7fffffffu);
-                    if (COUNT) c.hitupd++;
-                }
-                if (idl >> 31) {                                        // last triangle of the leaf: this node is done
-                    if (COUNT) c.nodes++;
-                    if (sp > 0) {
-                        cur = (int)stk[(--sp) * TPB];
-                        if (PACKED) { cur = (int)(((unsigned)cur | (hiA << 16)) << 14) >> 14; hiA = __builtin_amdgcn_alignbit(hiB, hiA, 2); hiB >>= 2; }
-                    } else cur = CUR_NONE;
-                } else {
-                    cur = cur - 1;                                      // next triangle record of the same leaf
-                    more = true;
-                }
-            }
-            if (__popcll(__ballot(more)) <= thr) mode = M_VOTE;
-        }
-    }
-#else
     for (;;) {
         // ---- refill idle lanes from the wave's range
         unsigned long long idle = __ballot(cur == CUR_IDLE);
@@ -490,13 +337,14 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 unsigned q = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 if (q < end) {
                     slot = queue ? queue[q] : q;
+                    *slotL = slot;
                     float4 g0 = st.G0[slot], g1 = st.G1[slot];
                     // both groups in ONE round trip (left alone the compiler fetches the flags word first and the rest behind the branch)
                     asm volatile("" : "+v"(g0.x), "+v"(g0.y), "+v"(g0.z), "+v"(g0.w), "+v"(g1.x), "+v"(g1.y), "+v"(g1.z), "+v"(g1.w));
                     const unsigned fl = __float_as_uint(g1.w);
                     if (fl & FL_ALIVE) {
                         d = v3(g0.w, g1.x, g1.y);
-                        probe = PROBES && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
+                        probe = RARE && (fl & FL_PROBE) != 0;             // directDiffuse's thickness probe: rayBVH called directly (:668); only RAYTRACING == 0 makes them
                         o = probe ? v3(g0.x, g0.y, g0.z) : madd(d, 1e-4f, v3(g0.x, g0.y, g0.z));   // o = o + 1e-4*d  (:549)
                         invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                         ob = probe ? probeObjOf(fl) : 0;
@@ -550,13 +398,13 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                         else t = rayEllipsoid(o, d, cc, E.r, E.st[0], E.st[1], E.st[2]);
                         if (t < closest) {
                             if (!(prim & PRIM_ELLIPSOID) || prim == PRIM_NONE) {                            // see intersectScene
-                                if (st.HX) st.HX[slot] = make_float4(hu, hv, __int_as_float(prim), 0.0f);
+                                if (RARE && st.HX) st.HX[*slotL] = make_float4(hu, hv, __int_as_float(prim), 0.0f);
                                 hu = __int_as_float(prim);
                             }
                             closest = t; prim = PRIM_ELLIPSOID | i;
                         }
                     }
-                    st.H[slot] = make_float4(closest, hu, hv, __int_as_float(prim));
+                    st.H[*slotL] = make_float4(closest, hu, hv, __int_as_float(prim));
                     cur = CUR_IDLE;
                 }
             }
@@ -633,7 +481,6 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
             } while (nMore > keepGoing);
         }
     }
-#endif
     if (COUNT) {
         atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
         atomicAdd(&ctl->cnt[PT_CNT_TRITESTS], (unsigned long long)c.tritests);
@@ -1262,7 +1109,9 @@ struct PoolRun {            // host view of the path pool while a batch runs
 template <bool COUNT, typename StackT, int TPB>
 void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int grid) {
     int nObjLds = std::min(sc.numObj, 8);
-    if (c->streamIn.params[9] != 1.0f) {                         // RAYTRACING of the running stream, not of a later upload
+    // the two rare features of the kernel are compiled into a variant of their own (their registers cost the common one spills):
+    // thickness probes (RAYTRACING == 0 of the running stream, not of a later upload) and the side record of mapped ellipsoids
+    if (c->streamIn.params[9] != 1.0f || c->ellipMaps) {
         hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB, true>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
                            c->innerKeepEighths, nObjLds, c->noneMin);
         return;
@@ -1275,7 +1124,7 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     DevScene sc = c->sc;
     int tpb = c->extendTpb;
     // LDS per block: [node tile][triangle tile][root-box distances][traversal stacks]; the tile takes what the fixed parts leave
-    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stackMode == 2 ? 4 : 2) + 64 + 32 * 8;     // + the LDS copies of up to 8 object roots
+    size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stackMode == 2 ? 4 : 2) + 64 + 32 * 8 + (size_t)tpb * 4;     // (+ the per-lane slot numbers)     // + the LDS copies of up to 8 object roots
     size_t avail = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
     size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, avail);
     {   // a smaller node tile (down to 6 KB) if that lets one more block — two more waves per SIMD — live on the CU: occupancy is worth

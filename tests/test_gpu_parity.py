@@ -434,6 +434,48 @@ def test_overlapped_batches_with_a_camera_move(pt, oracle, renderer_mod):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("name,change", [("C5", dict(RAYTRACING=0)), ("C3", dict(SAMPLE_RES=4, MAX_BOUNCES=2)), ("C3", dict(SAMPLE_RES=8, MAX_BOUNCES=12)), ("C5", dict(RAYTRACING=0, SAMPLE_RES=2))])
+def test_parameter_upload_between_overlapped_batches(pt, oracle, renderer_mod, name, change):
+    """pt_set_buffer(PT_BIND_PARAMS) while asynchronous batches are in flight (the reference's own loop drops SAMPLE_RES / MAX_BOUNCES to 4 / 2
+    while the camera moves, dispatch.java:646-666): the running stream finishes with the Parameters it was started with — kernel variant
+    (RAYTRACING), loop bounds, iteration budget — and the next batch starts a new stream with the new block"""
+    W, H = 96, 54
+    wl = pt.scenes.build(name, W, H)
+    wl2 = wl.with_params(**change)
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("path_slots", 2048)                           # small pool: a deep backlog is still unissued when the upload arrives
+    r.load_workload(wl)
+    r.reset_frame()
+    r.render_batch_async(1, [11, 22, 33])
+    r.set_buffer(4, wl2.buffers[4])                            # no flush here: the stream keeps running on the old block
+    r.render_batch_async(4, [44, 55])
+    r.set_buffer(4, wl.buffers[4])
+    r.render_batch_async(6, [66])
+    got = r.read_frame().copy()
+    r.close()
+    ref = np.zeros((H, W, 4), np.float32)
+    oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, 3, [11, 22, 33], frame=ref, nthreads=8)
+    oracle.render_frames(oracle.Scene.from_workload(wl2), W, H, 4, 2, [44, 55], frame=ref, nthreads=8)
+    oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 6, 1, [66], frame=ref, nthreads=8)
+    assert_same(got, ref)
+
+
+def test_debug_probe_does_not_disturb_batches_in_flight(pt, oracle, renderer_mod):
+    """pt_debug_intersect rewrites the frame constants (it forces AUTO_FOCUS = 0): work in flight is finished first"""
+    W, H = 96, 54
+    wl = pt.scenes.build("C3", W, H)
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("path_slots", 1024)
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch_async(1, [5, 6, 7])
+    r.debug_intersect(np.array([[0.0, 1.0, -3.0]], np.float32), np.array([[0.0, 0.0, 1.0]], np.float32))
+    r.render_batch_async(4, [8])
+    got = r.read_frame().copy()
+    r.close()
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, 4, [5, 6, 7, 8], nthreads=8)
+    assert_same(got, ref)
+
+
 def test_two_process_shards_on_one_gpu(pt):
     """one process per shard (as on the 8-GPU node), here 2 ranks sharing cuda:0, gloo collective"""
     import os, subprocess, sys
