@@ -268,7 +268,9 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 //   >= 0 and < CUR_NONE  inner node   |   < 0  leaf: first triangle record is -(cur+1)
 //   CUR_NONE  ray alive, BVH of the current object exhausted   |   CUR_IDLE  lane has no ray
 // (activity is folded into `cur` so that every wave-level vote is ONE v_cmp writing an SGPR pair)
-constexpr int CUR_NONE = 0x7ffffffe;
+//   CUR_DONE  ray finished, its hit record still in the lane's registers (stored at the wave's next refill)
+constexpr int CUR_NONE = 0x7ffffffd;
+constexpr int CUR_DONE = 0x7ffffffe;
 constexpr int CUR_IDLE = 0x7fffffff;
 // Traversal-stack entries (pending far children) live in LDS, one column per lane.  Their width decides how many blocks a CU holds:
 //   short     trees below 32767 inner nodes / triangle records
@@ -327,12 +329,15 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 #endif
     for (;;) {
         // ---- refill idle lanes from the wave's range
-        unsigned long long idle = __ballot(cur == CUR_IDLE);
+        unsigned long long idle = __ballot(cur >= CUR_DONE);                // lanes without a ray in flight
         int nIdle = __popcll(idle);
         PS(4, 64 - nIdle);
         if (pos < end && nIdle >= refillMin) {                              // wave-uniform
             PS(0, min(nIdle, (int)(end - pos)));
-            if (cur == CUR_IDLE) {
+            if (cur >= CUR_DONE) {
+                // the hit records of the rays that retired since the last refill leave together: one store instruction for all of them,
+                // neighbouring slots of one refill generation close in time (the lanes retire out of order)
+                if (cur == CUR_DONE) { st.H[*slotL] = make_float4(closest, hu, hv, __int_as_float(prim)); cur = CUR_IDLE; }
                 // rank of this lane among the idle ones: v_mbcnt (set bits of the mask below the lane), no lane-mask registers
                 unsigned q = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                 if (q < end) {
@@ -366,7 +371,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 }
             }
             pos += (unsigned)nIdle;
-            nIdle = __popcll(__ballot(cur == CUR_IDLE));
+            nIdle = __popcll(__ballot(cur >= CUR_DONE));
         }
         if (nIdle == 64) { if (pos >= end) break; continue; }
         // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire.  Like the two traversal
@@ -404,8 +409,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                             closest = t; prim = PRIM_ELLIPSOID | i;
                         }
                     }
-                    st.H[*slotL] = make_float4(closest, hu, hv, __int_as_float(prim));
-                    cur = CUR_IDLE;
+                    cur = CUR_DONE;
                 }
             }
             nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));
@@ -481,6 +485,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
             } while (nMore > keepGoing);
         }
     }
+    if (cur == CUR_DONE) st.H[*slotL] = make_float4(closest, hu, hv, __int_as_float(prim));      // the rays that retired after the last refill
     if (COUNT) {
         atomicAdd(&ctl->cnt[PT_CNT_NODES], (unsigned long long)c.nodes);
         atomicAdd(&ctl->cnt[PT_CNT_TRITESTS], (unsigned long long)c.tritests);
