@@ -3,11 +3,15 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+Every GPU runs --streams (default 2) independent wavefront streams — tile shards with their own path pool and HIP stream whose
+kernels overlap freely (pt_create_multi with a device listed twice): the intersect kernel of one stream is instruction-issue bound,
+the shading kernel of the other HBM bound, and the launch tails fill (C3 +9 %, C4 +24 % over one stream).
 N > 1 runs in either of two forms, same tile sharding, same single RCCL gather per image:
-  * started plainly (`python bench.py --gpus N`): ONE process, ONE multi-GPU context behind the C ABI (pt_create_multi: a host
-    thread per device inside the library, ncclGather on device 0) — what the reference's single-threaded Java host would call;
-  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's scaling runs): one process per GPU,
-    torch.distributed "nccl" (= RCCL) gather of the library's packed accumulators, barrier + max-over-ranks timing.
+  * started plainly (`python bench.py --gpus N`): ONE process, ONE context behind the C ABI (pt_create_multi: a host thread per
+    stream inside the library, ncclGather on device 0) — what the reference's single-threaded Java host would call;
+  * under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the driver's scaling runs): one process per GPU
+    (pt_create_multi_part: its streams are shards rank*K .. rank*K+K-1 of N*K), torch.distributed "nccl" (= RCCL) gather of the packed
+    blocks, the library's un-tiling kernel on rank 0, barrier + max-over-ranks timing.
 
 One step = one image of the workload: `frames_per_step` frames x SAMPLE_RES samples/pixel over the whole W x H image (tile-sharded
 over the N GPUs) and the single gather of the accumulated framebuffer on GPU 0.  Consecutive steps overlap on the GPU (a step's
@@ -47,6 +51,7 @@ def parse():
     ap.add_argument("--path-slots", type=int, default=None)
     ap.add_argument("--sync", action="store_true", help="drain the path pool at the end of every step (pt_render_batch) instead of overlapping consecutive steps")
     ap.add_argument("--max-batch", type=int, default=32, help="frames per wavefront batch (bounds the per-frame staging buffer: 16 B x pixels x frames)")
+    ap.add_argument("--streams", type=int, default=2, help="independent wavefront streams per GPU (each a tile shard with its own path pool and HIP stream)")
     ap.add_argument("--devices", default=None, help="single-process multi-GPU context on these HIP devices, e.g. 0,1,2,3 (default 0..N-1); a device listed "
                                                     "twice (0,0) rehearses the sharding on one GPU (gather by device copies: RCCL refuses duplicate devices)")
     ap.add_argument("--dist", action="store_true", help="take the torch.distributed path even at WORLD_SIZE 1 (exercises the RCCL gather of the process-per-GPU form on one GPU)")
@@ -59,7 +64,7 @@ def parse():
     return ap.parse_args()
 
 
-def roofline_block(args, r, stats, samples, world, dt, value, sample_res):
+def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus=1):
     """Per-kernel bounds, each recomputable from tracked files: the per-segment counter figures come from the committed rocprofv3
     summary profiles/pmc_<config>.json (scripts/pmc_all.sh: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, FETCH_SIZE, WRITE_SIZE ... per
     segment), the segments per launch and the launch durations are measured live (statistics pass + HIP events on the launch stream)."""
@@ -107,6 +112,18 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res):
     # the device-private BVH is served from LDS and L2, so this is NOT a fraction of any roof of this kernel
     b_ext = Q_EXTEND + nv * 44 + tt * 36 + hu * 124
     b_samp = S * 304 + S * (nv * 44 + tt * 36 + hu * 124) + 32.0 / sample_res
+    # The streams of a GPU run their kernels concurrently, so a launch shares the chip with the other stream's launches: the per-launch
+    # figures above are what ONE stream's kernel reaches; what the chip reaches is the sum over everything in flight — total instructions /
+    # bytes of the timed region over its wall time, per GPU.
+    if ke and ks and "valu_per_segment" in ke and "valu_per_segment" in ks:
+        v = (ke["valu_per_segment"] + ks["valu_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
+        chip = {"streams_per_gpu": max(world // max(n_gpus, 1), 1), "kernel_concurrency": round((ms_ext + ms_sh) / (dt * 1e3) / max(n_gpus, 1), 3),
+                "valu_issue": {"achieved": round(v, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": round(v / VALU_PEAK_GINST, 4)},
+                "note": "whole timed region, both kernels: (VALU instructions per segment of k_extend_persist + k_shade) x segments / wall time / GPUs; likewise HBM bytes"}
+        if "hbm_bytes_per_segment" in ke and "hbm_bytes_per_segment" in ks:
+            b = (ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
+            chip["hbm"] = {"achieved": round(b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / HBM_PEAK_GBS, 4)}
+        out["chip"] = chip
     out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "extend_GBps_if_streamed": round(b_ext * seg_rate / 1e9, 1),
                           "bytes_per_sample_whole_path": round(b_samp, 1), "whole_path_GBps": round(b_samp * value * 1e6 / 1e9 / world, 1),
                           "note": "SURVEY.md 8(d): 44 B per node visit, 36 B per triangle test, 124 B per hit update, 304 B of queue state per segment in the reference's "
@@ -123,7 +140,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if dist_mode else 0
     if dist_mode and env_world is not None and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: torch.distributed.run --nproc-per-node must equal --gpus")
-    multi = (not dist_mode) and (args.gpus > 1 or args.devices is not None) and not args.rehearse_shard
+    K = max(1, args.streams)
+    multi = (not dist_mode) and (args.gpus > 1 or args.devices is not None or K > 1) and not args.rehearse_shard
 
     import numpy as np
     import torch
@@ -151,50 +169,56 @@ def main():
     wl = scenes.build(args.config, W, H)
 
     if multi:
-        devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        devices = [int(d) for d in args.devices.split(",")] if args.devices else [d for d in range(args.gpus) for _ in range(K)]
         n_gpus = len(set(devices))
         r = renderer.Renderer(W, H, devices=devices)
         shards = len(devices)
+    elif dist_mode:
+        devices = [local_rank] * K                  # this rank's streams = tile shards rank*K .. rank*K+K-1 of world*K
+        r = renderer.Renderer(W, H, devices=devices, first_shard=rank * K, total_shards=world * K)
+        n_gpus, shards = world, world * K
     else:
-        shard_rank, shard_count = (rank, world) if not args.rehearse_shard else tuple(args.rehearse_shard)
+        shard_rank, shard_count = (0, 1) if not args.rehearse_shard else tuple(args.rehearse_shard)
         r = renderer.Renderer(W, H, device=local_rank, shard_rank=shard_rank, shard_count=shard_count)
-        n_gpus, shards = world, shard_count
+        n_gpus, shards = 1, shard_count
     if args.path_slots:
         r.set_option("path_slots", args.path_slots)
     for name, val in (("lds_budget", args.lds_budget), ("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache),
                       ("refill_min", args.refill_min), ("none_min", args.none_min), ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep), ("bfs_nodes", args.bfs_nodes), ("stack_mode", args.stack_mode)):
         if val is not None:
             r.set_option(name, val)
-    if not multi:
-        stream = torch.cuda.Stream(dev)         # one explicit HIP stream for kernels AND the collective (the null stream cannot be handed over)
-        torch.cuda.set_stream(stream)
-        r.set_stream(stream.cuda_stream)
     r.load_workload(wl)
     r.reset_frame()
 
+    unshard = None
     if multi:
         full_view = lambda ptr: torch.as_tensor(shard._DevArray(ptr, (H, W, 4)), device=torch.device("cuda", devices[0]))      # noqa: E731
         collect = lambda age: full_view(r.gather_image(age))                                                                     # noqa: E731
-        unshard = None
         collect(0)                              # untimed: RCCL builds its communicators and rings on the first collective
         r.synchronize()
+    elif dist_mode:
+        # this rank's block: its K packed shard accumulators (world 1: the group holds the whole image and hands it over un-tiled)
+        n_block = K * renderer.shard_slots(W, H, world * K) if world > 1 else W * H
+        unshard = shard.Unsharder(W, H, world * K if world > 1 else 1, renderer.shard_map, dev, renderer=r, ranks=world, sync_before_unshard=True)
+
+        def collect(age):                       # the library completes the image and packs this rank's block, RCCL gathers the blocks
+            packed = torch.as_tensor(shard._DevArray(r.gather_image(age), (n_block, 4)), device=dev)
+            r.stream_wait()                     # the block was written on the library's stream; torch's collective runs on another
+            return shard.gather_frame(packed, unshard, dst=0, force_collective=True)
+        collect(0)                              # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
+        torch.cuda.synchronize(dev)
     else:
-        collect = None
         if args.rehearse_shard:
-            unshard = lambda t: t               # noqa: E731
-            unshard.world = 1
+            collect = lambda age: (r.finish_image(age), shard.frame_tensor(r, dev, age))[1]      # noqa: E731
         else:
-            unshard = shard.Unsharder(W, H, world, renderer.shard_map, dev, renderer=r)
-        if dist_mode:                           # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
-            shard.gather_frame(torch.zeros_like(shard.frame_tensor(r, dev)), unshard, dst=0, force_collective=True)
-            torch.cuda.synchronize(dev)
+            collect = lambda age: torch.as_tensor(shard._DevArray(r.gather_image(age), (H, W, 4)), device=dev)      # noqa: E731
 
     MAX_BATCH = args.max_batch
     # One step = one image: reset, spp_step samples per pixel, ONE framebuffer gather.  Consecutive steps overlap on the GPU:
     # a step's last paths finish underneath the next step's first ones (pt_render_batch_async / pt_next_image), and its
     # image is gathered while the next one renders.  Every step's work and gather lie inside the timed region; the fence
     # completes everything that is still in flight.
-    pipeline = shard.StepPipeline(r, unshard, dev, lag=2, collect=collect, force_collective=dist_mode)      # an image is gathered two steps after it was submitted
+    pipeline = shard.StepPipeline(r, unshard, dev, lag=2, collect=collect)      # an image is gathered two steps after it was submitted
 
     def submit():
         done = 0
@@ -212,9 +236,7 @@ def main():
         if args.sync:
             r.reset_frame()
             submit()
-            if multi:
-                return collect(0)
-            return shard.gather_frame(shard.frame_tensor(r, dev), unshard, dst=0, force_collective=dist_mode)
+            return collect(0)
         return pipeline.step(submit)
 
     def drain():
@@ -272,12 +294,14 @@ def main():
         samples = float((renderer.shard_map(W, H, shard_rank, shard_count) >= 0).sum()) * spp_step * args.steps
     value = samples / dt / 1e6
 
+    per_gpu = f"{shards // max(n_gpus, 1)} independent wavefront stream(s) per GPU"
     if multi:
-        how = f"ONE process, pt_create_multi on devices {devices}: {'RCCL ncclGather' if n_gpus == shards else 'device-copy gather (devices repeat: rehearsal)'} on device {devices[0]}"
+        how = (f"ONE process, pt_create_multi on devices {devices} ({per_gpu}): " +
+               ("device copies between the streams of a GPU, RCCL ncclGather across GPUs, un-tiling on device " if n_gpus > 1 else "device copies between the streams, un-tiling on device ") + str(devices[0]))
     elif dist_mode:
-        how = f"one process per GPU (torch.distributed nccl = RCCL), dist.gather on rank 0, world {world}"
+        how = f"one process per GPU, {per_gpu} (pt_create_multi_part), torch.distributed nccl (= RCCL) dist.gather of the packed blocks on rank 0, pt_unshard there; world {world}"
     else:
-        how = "one GPU, no collective"
+        how = "one GPU, one stream, no collective"
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -288,8 +312,6 @@ def main():
     }
     if args.rehearse_shard:
         out["rehearsal"] = f"shard {shard_rank} of {shard_count} alone on one GPU: value is THIS shard's rate, not a multi-GPU measurement"
-    if multi and n_gpus != shards:
-        out["rehearsal"] = f"{shards} shards on {n_gpus} GPU(s): exercises the multi-GPU context's bookkeeping, not a scaling measurement"
     if stats is not None:
         if dist_mode and world > 1:             # launches and device time of all ranks, like the multi-GPU context reports them
             acc = []
@@ -311,9 +333,9 @@ def main():
             src = _All()
         else:
             src = r
-        out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res)
+        out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res, n_gpus=n_gpus)
 
-    if rank == 0 and n_gpus == 1 and shards == 1 and not dist_mode and not multi and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not dist_mode and not args.rehearse_shard and not args.no_cpu_baseline:
         # the reference has no CPU render path: the timed CPU baseline is the oracle ("port")
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle

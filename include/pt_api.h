@@ -55,14 +55,22 @@ enum {
  * shard_rank / shard_count select the tile shard this context renders (1 GPU: 0 / 1): the image
  * is cut into 32x8-pixel tiles dealt round-robin to the ranks. */
 int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, int shard_count);
-/* ONE context for several GPUs of the node (SURVEY.md §8(b) "pt_create(backend, n_devices, W, H)", §8(e)): what the reference's
- * single thread owning the single GL context (dispatch.java:168, :593-713) can drive.  Every entry point below works on it:
- * uploads replicate the scene on devices[0..n), the render calls render each device's tile shard concurrently (one host thread
- * per device inside the library), and pt_read_frame / pt_read_display / pt_gather_image perform the ONE collective of an image —
- * an RCCL gather (ncclGather, single process, ncclCommInitAll) of the packed accumulators on devices[0] — and un-tile it there.
- * Results are bit-identical to a one-GPU context.  A device listed more than once is a rehearsal of the sharding on fewer GPUs
- * than shards (RCCL refuses two ranks on one device): the gather then uses device-to-device copies. */
+/* ONE context made of several wavefront streams (SURVEY.md §8(b) "pt_create(backend, n_devices, W, H)", §8(e)): what the reference's
+ * single thread owning the single GL context (dispatch.java:168, :593-713) can drive.  devices[] names the HIP device of every stream:
+ *   {0,1,...,7}      all GPUs of the node, one stream each;
+ *   {0,0}            TWO independent streams on one GPU — each with its own path pool and HIP stream, unsynchronised, so the intersect
+ *                    kernel of one (issue/latency bound) overlaps the shading kernel of the other (HBM bound) and the launch tails fill:
+ *                    9-24 % faster than one stream;
+ *   {0,0,1,1,...}    both (a device's entries adjacent, every device the same number of times).
+ * Every entry point below works on it: uploads replicate the scene, the render calls render every stream's tile shard concurrently
+ * (one host thread per stream inside the library), and pt_read_frame / pt_read_display / pt_gather_image perform the ONE collective
+ * of an image — device copies between the streams of a device, ONE RCCL gather (ncclGather, single process, ncclCommInitAll) across
+ * devices, un-tiling on devices[0].  Results are bit-identical to a one-stream context. */
 int pt_create_multi(pt_ctx** out, const int* devices, int n_devices, int width, int height);
+/* The same for a PART of the image: the group's n streams are tile shards first_shard .. first_shard+n-1 of total_shards (one process
+ * per GPU, each with several streams on its GPU).  pt_gather_image then delivers the group's packed block — n * pt_shard_slots(W, H,
+ * total_shards) accumulators, shard-major — for the host layer's gather across processes; pt_unshard un-tiles the gathered blocks. */
+int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int width, int height, int first_shard, int total_shards);
 int pt_destroy(pt_ctx* ctx);
 const char* pt_last_error(void);
 
@@ -102,13 +110,16 @@ int pt_finish_image(pt_ctx* ctx, int age);
 /* Device pointer of the FRAME image `age` pt_next_image calls ago (0 = current), layout as pt_frame_device (one-device contexts). */
 int pt_image_device(pt_ctx* ctx, int age, void** dev_ptr, size_t* n_pixels);
 /* The whole FRAME image `age` pt_next_image calls ago as width*height RGBA32F in device memory (row 0 = bottom): completes that
- * image like pt_finish_image and, on a multi-GPU context, performs its ONE collective (RCCL gather of the shard accumulators on
- * devices[0] + un-tiling kernel; stream-ordered there, not synchronised; the buffer is reused by the next gather).  On a
- * one-device context it is that context's own image. */
+ * image like pt_finish_image and, on a pt_create_multi context, performs its ONE collective (device copies + RCCL gather of the shard
+ * accumulators on devices[0] + un-tiling kernel; stream-ordered there, not synchronised; the buffer is reused by the next gather).
+ * On a one-stream context it is that context's own image; on a pt_create_multi_part context the group's packed block. */
 int pt_gather_image(pt_ctx* ctx, int age, void** full_dev);
 
 /* glFinish() (dispatch.java:598) */
 int pt_synchronize(pt_ctx* ctx);
+/* Waits for what is already enqueued on the context's HIP stream(s) — an accumulation, a gather, an un-tiling — WITHOUT completing
+ * the batches still in flight (pt_synchronize does that): what a host layer calls between pt_gather_image and a collective of its own. */
+int pt_stream_wait(pt_ctx* ctx);
 
 /* glReadPixels-like read-back of the FRAME image as width*height RGBA32F, row 0 = bottom
  * (rgb = running sum, a = frame count; frag.glsl:924-933).  Synchronises.  A multi-GPU context

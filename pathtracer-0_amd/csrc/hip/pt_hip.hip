@@ -1482,17 +1482,28 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
     return PT_OK;
 }
 
-int pt_create_multi(pt_ctx** out, const int* devices, int n_devices, int width, int height) {
-    if (!out || !devices || n_devices < 1 || n_devices > 64 || width < 1 || height < 1) return fail(PT_ERR_ARG, "pt_create_multi: bad argument");
+int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int width, int height, int first_shard, int total_shards) {
+    if (!out || !devices || n_devices < 1 || n_devices > 64 || width < 1 || height < 1 || first_shard < 0 || total_shards < n_devices || first_shard + n_devices > total_shards)
+        return fail(PT_ERR_ARG, "pt_create_multi: bad argument");
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     for (int i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= nDev) return fail(PT_ERR_NO_DEVICE, "pt_create_multi: HIP device index out of range");
+    // the streams of one device are adjacent entries, every device carries the same number of them
+    std::vector<MultiCtx::Run> runs;
+    for (int i = 0; i < n_devices; i++) {
+        if (!runs.empty() && runs.back().device == devices[i]) { runs.back().count++; continue; }
+        for (const auto& r : runs) if (r.device == devices[i]) return fail(PT_ERR_ARG, "pt_create_multi: the entries of one device must be adjacent ({0,0,1,1}, not {0,1,0,1})");
+        runs.push_back(MultiCtx::Run{devices[i], i, 1, nullptr});
+    }
+    for (const auto& r : runs) if (r.count != runs[0].count) return fail(PT_ERR_ARG, "pt_create_multi: every device must be listed the same number of times");
     pt_ctx* g = new pt_ctx();
     g->W = width; g->H = height; g->device = devices[0];
     MultiCtx* M = new MultiCtx();
     g->multi = M;
-    M->n = n_devices; M->devices.assign(devices, devices + n_devices);
-    for (int i = 0; i < n_devices; i++) for (int j = 0; j < i; j++) if (devices[i] == devices[j]) M->sameDevice = true;
+    M->n = n_devices; M->devices.assign(devices, devices + n_devices); M->runs = runs;
+    M->shardBase = first_shard; M->shardTotal = total_shards;
+    const char* force = getenv("PT_MULTI_FORCE_RCCL");          // tests: the RCCL call path of a one-device group on a one-GPU box
+    M->useRccl = runs.size() > 1 || (force && force[0] == '1');
     M->kids.assign(n_devices, nullptr);
     for (int i = 0; i < n_devices; i++) {
         M->workers.emplace_back(new Worker());
@@ -1501,13 +1512,17 @@ int pt_create_multi(pt_ctx** out, const int* devices, int n_devices, int width, 
     }
     for (int i = 0; i < n_devices; i++) {
         pt_ctx** slot = &M->kids[i]; const int dev = devices[i];
-        M->workers[i]->post([=] { return pt_create(slot, dev, width, height, i, n_devices); });
+        M->workers[i]->post([=] { return pt_create(slot, dev, width, height, first_shard + i, total_shards); });
     }
     int rc = 0; std::string err;
     for (int i = 0; i < n_devices; i++) { int r = M->workers[i]->wait(); if (r && !rc) { rc = r; err = "device " + std::to_string(devices[i]) + ": " + M->workers[i]->err; } }
     if (rc) { M->kids.erase(std::remove(M->kids.begin(), M->kids.end(), nullptr), M->kids.end()); multiFree(g); delete g; return fail(rc, err); }
     *out = g;
     return PT_OK;
+}
+
+int pt_create_multi(pt_ctx** out, const int* devices, int n_devices, int width, int height) {
+    return pt_create_multi_part(out, devices, n_devices, width, height, 0, n_devices);
 }
 
 int pt_destroy(pt_ctx* c) {
@@ -1631,15 +1646,32 @@ int pt_synchronize(pt_ctx* c) {
     return PT_OK;
 }
 
+int pt_stream_wait(pt_ctx* c) {
+    if (!c) return fail(PT_ERR_ARG, "null context");
+    if (c->multi) { for (pt_ctx* k : c->multi->kids) { int rc = pt_stream_wait(k); if (rc) return rc; } return PT_OK; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 int pt_read_frame(pt_ctx* c, float* out) {
     if (!c || !out) return fail(PT_ERR_ARG, "pt_read_frame: null argument");
-    if (c->multi) {                                               // the ONE collective: RCCL gather on device[0], un-tile, read back
+    if (c->multi) {                                               // the ONE collective: gather on devices[0], un-tile, read back
         float4* full = nullptr;
         int rc = multiGather(c, 0, &full);
         if (rc) return rc;
-        pt_ctx* root = c->multi->kids[0];
-        HIP_TRY(hipMemcpyAsync(out, full, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, root->stream));
+        MultiCtx& M = *c->multi;
+        pt_ctx* root = M.kids[0];
+        if (M.shardTotal == M.n) {
+            HIP_TRY(hipMemcpyAsync(out, full, (size_t)c->W * c->H * 16, hipMemcpyDeviceToHost, root->stream));
+            HIP_TRY(hipStreamSynchronize(root->stream));
+            return PT_OK;
+        }
+        // a part of the image (pt_create_multi_part): only this group's pixels are written, like a single shard context
+        std::vector<float> tmp(M.maps.size() * 4);
+        HIP_TRY(hipMemcpyAsync(tmp.data(), full, tmp.size() * 4, hipMemcpyDeviceToHost, root->stream));
         HIP_TRY(hipStreamSynchronize(root->stream));
+        for (size_t k = 0; k < M.maps.size(); k++) if (M.maps[k] >= 0) std::memcpy(out + 4 * (size_t)M.maps[k], tmp.data() + 4 * k, 16);
         return PT_OK;
     }
     HIP_TRY(hipSetDevice(c->device));
@@ -1661,6 +1693,7 @@ int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out
     if (!c || !rgb_out) return fail(PT_ERR_ARG, "pt_read_display: null argument");
     const float4* frame = nullptr; pt_ctx* on = c;
     if (c->multi) {
+        if (c->multi->shardTotal != c->multi->n) return fail(PT_ERR_ARG, "pt_read_display needs the whole image: this group holds a part of it (pt_create_multi_part)");
         float4* full = nullptr;
         int rc = multiGather(c, 0, &full);
         if (rc) return rc;
@@ -1719,7 +1752,10 @@ int pt_shard_map(int width, int height, int shard_rank, int shard_count, int32_t
 
 int pt_unshard(pt_ctx* c, const void* gathered_dev, void* full_dev) {
     if (!c || !gathered_dev || !full_dev) return fail(PT_ERR_ARG, "pt_unshard: null argument");
-    if (c->multi) return fail(PT_ERR_ARG, "pt_unshard: a multi-GPU context gathers and un-tiles by itself (pt_gather_image, pt_read_frame)");
+    if (c->multi) {
+        if (c->multi->shardTotal == c->multi->n) return fail(PT_ERR_ARG, "pt_unshard: a whole-image context gathers and un-tiles by itself (pt_gather_image, pt_read_frame)");
+        c = c->multi->kids[0];                                    // a part of the image: any of its shards knows the layout of all shard_total blocks
+    }
     HIP_TRY(hipSetDevice(c->device));
     size_t total = (size_t)c->nSlotsImg * c->shardCount;
     if (!c->dAllMaps) {

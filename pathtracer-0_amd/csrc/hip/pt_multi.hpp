@@ -1,19 +1,23 @@
-// pt_multi.hpp — the multi-GPU form of a render context, behind the same C ABI (included by pt_hip.hip).
+// pt_multi.hpp — a render context made of several wavefront streams, behind the same C ABI (included by pt_hip.hip).
 //
-// The reference is ONE host thread that owns ONE GL context and issues one draw call per frame
-// (/root/reference/src/Main/dispatch.java:168, :593-713).  A caller of that shape (the Java Main through the JNI shim, a C
-// program) gets all GPUs of the node through ONE context: pt_create_multi(devices[], n, W, H) makes a group whose entry points
-// are the ordinary ones — pt_set_buffer replicates the scene, pt_render / pt_render_batch(_async) render every device's tile
-// shard (32x8 tiles dealt round-robin), pt_read_frame / pt_gather_image perform the ONE collective per image:
-// an RCCL gather (ncclGather over xGMI, single process, ncclCommInitAll) of the packed shard accumulators on device[0] and the
-// un-tiling kernel there.  No exchange during rendering; results are bit-identical for every device count (K10).
+// Two uses of one mechanism:
+//  * several GPUs.  The reference is ONE host thread that owns ONE GL context and issues one draw call per frame
+//    (/root/reference/src/Main/dispatch.java:168, :593-713).  A caller of that shape (the Java Main through the JNI shim, a C
+//    program) gets all GPUs of the node through ONE context: pt_create_multi(devices[], n, W, H) makes a group whose entry points
+//    are the ordinary ones — pt_set_buffer replicates the scene, pt_render / pt_render_batch(_async) render every stream's tile
+//    shard (32x8 tiles dealt round-robin), pt_read_frame / pt_gather_image perform the ONE collective per image:
+//    an RCCL gather (ncclGather over xGMI, single process, ncclCommInitAll) of the packed shard accumulators on devices[0] and the
+//    un-tiling kernel there.  No exchange during rendering; results are bit-identical for every stream count (K10).
+//  * several streams on ONE GPU: a device listed k times carries k shards, each with its own path pool and HIP stream.  The
+//    streams run unsynchronised, so the intersect kernel of one (instruction-issue and latency bound) overlaps the shading kernel of
+//    another (HBM bound) and every launch's tail is filled by the other stream's blocks: two streams per GPU render C3 9 %, C4
+//    24 % faster than one (profiles/r02_g_streams_per_gpu.txt).  Shards that share a device are gathered with device copies.
+//  The two combine ({0,0,1,1,...}: equal multiplicity, a device's entries adjacent): per device its shards are copied into one
+//  staging block, the blocks travel in the one ncclGather.  pt_create_multi_part makes a group that holds only shards
+//  first..first+n-1 of a larger total (one process per GPU, each with its own streams): its gather stops at the packed block.
 //
-// Host side: each device's context is driven by its own host thread (the wavefront scheduler polls its device, pump()), so the N
-// schedulers run concurrently; the group's entry points hand the call to the N threads and join them.
-//
-// A device listed more than once ({0,0}: two shards on one GPU) is a rehearsal of the sharding on fewer GPUs than shards — RCCL
-// refuses two ranks on one device — and gathers with device-to-device copies instead; the bookkeeping (shard maps, padding,
-// un-tiling, image ring) is the same code.
+// Host side: every stream's context is driven by its own host thread (the wavefront scheduler polls its device, pump()), so the
+// schedulers run concurrently; the group's entry points hand the call to the threads and join them.
 #pragma once
 #include <condition_variable>
 #include <dlfcn.h>
@@ -79,17 +83,20 @@ struct Worker {                     // one host thread per device context
 }  // namespace
 
 struct MultiCtx {
-    int n = 0;
-    std::vector<int> devices;
+    int n = 0;                          // streams (shards held by this group)
+    int shardBase = 0, shardTotal = 0;  // they are shards shardBase .. shardBase+n-1 of shardTotal (== n: the whole image)
+    std::vector<int> devices;           // per stream; equal entries adjacent
     std::vector<pt_ctx*> kids;
-    bool sameDevice = false;
+    struct Run { int device, first, count; float4* staging; };      // the streams of one device
+    std::vector<Run> runs;
+    bool useRccl = false;               // more than one distinct device (or PT_MULTI_FORCE_RCCL=1: the RCCL call path on a one-GPU box)
     std::vector<std::unique_ptr<Worker>> workers;
-    std::vector<ncclComm_t> comms;
-    std::vector<hipEvent_t> ev;         // copy path: "this shard's image is complete" on the shard's stream
-    float4* dGathered = nullptr;        // on devices[0]: n * nSlots packed accumulators, rank-major (what ncclGather delivers)
-    float4* dFull = nullptr;            // on devices[0]: W * H, un-tiled
+    std::vector<ncclComm_t> comms;      // one per run
+    std::vector<hipEvent_t> ev;         // per stream: "this shard's image is complete"; ev[run.first] doubles as "the copies have read it"
+    float4* dGathered = nullptr;        // on devices[0]: n * nSlots packed accumulators, shard-major (what the gather delivers)
+    float4* dFull = nullptr;            // on devices[0]: W * H, un-tiled (whole-image groups)
     int* dAllMaps = nullptr;            // on devices[0]: packed slot -> global pixel, -1 = padding
-    unsigned char* dDisplay = nullptr;
+    std::vector<int32_t> maps;          // the same on the host (pt_read_frame of a partial group)
     uint64_t gathers = 0;
 };
 
@@ -117,19 +124,21 @@ void multiFree(pt_ctx* g) {
     if (!M->devices.empty()) hipSetDevice(M->devices[0]);
     for (ncclComm_t c : M->comms) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
     for (hipEvent_t e : M->ev) if (e) hipEventDestroy(e);
-    for (void* p : {(void*)M->dGathered, (void*)M->dFull, (void*)M->dAllMaps, (void*)M->dDisplay}) if (p) hipFree(p);
+    for (void* p : {(void*)M->dGathered, (void*)M->dFull, (void*)M->dAllMaps}) if (p) hipFree(p);
+    for (auto& r : M->runs) if (r.staging) { hipSetDevice(r.device); hipFree(r.staging); }
     delete M;
     g->multi = nullptr;
 }
 
-// The ONE collective of an image: every shard completes image `age`, its packed accumulator goes to devices[0] (RCCL gather over
-// xGMI), and the un-tiling kernel writes the full W x H image there.  Stream-ordered on the root shard's stream.
-int multiGather(pt_ctx* g, int age, float4** fullOut) {
+// The ONE collective of an image: every stream completes image `age`; the shards of one device are copied into one block there, the
+// blocks go to devices[0] (ncclGather over xGMI when there are several devices), and — for a group that holds the whole image —
+// the un-tiling kernel writes the W x H image.  Stream-ordered on the root stream (kids[0]'s), not synchronised.
+// *out: the whole image (shardTotal == n) or the group's packed block of n * nSlots accumulators, shard-major.
+int multiGather(pt_ctx* g, int age, float4** out) {
     MultiCtx& M = *g->multi;
     int rc;
     if ((rc = multiRun(M, [age](pt_ctx* k) { return pt_finish_image(k, age); }))) return rc;
     pt_ctx* root = M.kids[0];
-    HIP_TRY(hipSetDevice(M.devices[0]));
     const size_t nSlots = (size_t)root->nSlotsImg, total = nSlots * (size_t)M.n;
     std::vector<float4*> img(M.n);
     for (int i = 0; i < M.n; i++) {
@@ -137,49 +146,65 @@ int multiGather(pt_ctx* g, int age, float4** fullOut) {
         img[i] = k->dImage[(k->curImage + pt_ctx::IMAGES - age) % pt_ctx::IMAGES];
         if (!img[i]) return fail(PT_ERR_ARG, "no image of that age yet (too few pt_next_image calls)");
     }
+    HIP_TRY(hipSetDevice(M.devices[0]));
     if (!M.dGathered) {
         HIP_TRY(hipMalloc((void**)&M.dGathered, total * 16));
-        HIP_TRY(hipMalloc((void**)&M.dFull, (size_t)g->W * g->H * 16));
-        std::vector<int32_t> maps(total);
-        for (int r = 0; r < M.n; r++) if ((rc = pt_shard_map(g->W, g->H, r, M.n, maps.data() + (size_t)r * nSlots, nSlots))) return rc;
-        HIP_TRY(hipMalloc((void**)&M.dAllMaps, total * 4));
-        HIP_TRY(hipMemcpy(M.dAllMaps, maps.data(), total * 4, hipMemcpyHostToDevice));
+        M.maps.resize(total);
+        for (int r = 0; r < M.n; r++) if ((rc = pt_shard_map(g->W, g->H, M.shardBase + r, M.shardTotal, M.maps.data() + (size_t)r * nSlots, nSlots))) return rc;
+        if (M.shardTotal == M.n) {
+            HIP_TRY(hipMalloc((void**)&M.dFull, (size_t)g->W * g->H * 16));
+            HIP_TRY(hipMalloc((void**)&M.dAllMaps, total * 4));
+            HIP_TRY(hipMemcpy(M.dAllMaps, M.maps.data(), total * 4, hipMemcpyHostToDevice));
+        }
+        M.ev.assign(M.n, nullptr);
+        for (int i = 0; i < M.n; i++) { HIP_TRY(hipSetDevice(M.devices[i])); HIP_TRY(hipEventCreateWithFlags(&M.ev[i], hipEventDisableTiming)); }
+        HIP_TRY(hipSetDevice(M.devices[0]));
     }
-    if (!M.sameDevice) {
+    // 1. per device: its streams' accumulators side by side, on the device's first stream (one stream: nothing to copy).  Without RCCL
+    //    (one device) the block IS the gathered buffer.
+    for (auto& run : M.runs) {
+        if (run.count == 1 && M.useRccl) continue;
+        HIP_TRY(hipSetDevice(run.device));
+        pt_ctx* lead = M.kids[run.first];
+        float4* dst = M.useRccl ? run.staging : M.dGathered + (size_t)run.first * nSlots;
+        if (M.useRccl && !dst) { HIP_TRY(hipMalloc((void**)&run.staging, (size_t)run.count * nSlots * 16)); dst = run.staging; }
+        for (int j = 0; j < run.count; j++) {
+            const int i = run.first + j;
+            if (j > 0) { HIP_TRY(hipEventRecord(M.ev[i], M.kids[i]->stream)); HIP_TRY(hipStreamWaitEvent(lead->stream, M.ev[i], 0)); }
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)j * nSlots, img[i], nSlots * 16, hipMemcpyDeviceToDevice, lead->stream));
+        }
+        // the other streams must not rotate their image rings past this image before the copies have read it
+        if (run.count > 1) {
+            HIP_TRY(hipEventRecord(M.ev[run.first], lead->stream));
+            for (int j = 1; j < run.count; j++) HIP_TRY(hipStreamWaitEvent(M.kids[run.first + j]->stream, M.ev[run.first], 0));
+        }
+    }
+    // 2. across devices: ONE ncclGather, a block per device, root = devices[0]
+    if (M.useRccl) {
         if ((rc = g_rccl.load())) return rc;
         if (M.comms.empty()) {
-            M.comms.assign(M.n, nullptr);
-            RCCL_TRY(g_rccl.CommInitAll(M.comms.data(), M.n, M.devices.data()));
+            std::vector<int> devs;
+            for (auto& run : M.runs) devs.push_back(run.device);
+            M.comms.assign(M.runs.size(), nullptr);
+            RCCL_TRY(g_rccl.CommInitAll(M.comms.data(), (int)devs.size(), devs.data()));
         }
         RCCL_TRY(g_rccl.GroupStart());
-        for (int i = 0; i < M.n; i++) {
-            HIP_TRY(hipSetDevice(M.devices[i]));
+        for (size_t r = 0; r < M.runs.size(); r++) {
+            const auto& run = M.runs[r];
+            HIP_TRY(hipSetDevice(run.device));
+            const float4* send = run.count == 1 ? img[run.first] : run.staging;
             // recvbuff matters on the root only; the other ranks pass a valid local pointer that is never written
-            ncclResult_t r = g_rccl.Gather(img[i], i == 0 ? (void*)M.dGathered : (void*)img[i], nSlots * 4, ncclFloat, 0, M.comms[i], M.kids[i]->stream);
-            if (r != ncclSuccess) { g_rccl.GroupEnd(); return fail(PT_ERR_HIP, std::string("ncclGather: ") + g_rccl.GetErrorString(r)); }
+            ncclResult_t e = g_rccl.Gather(send, r == 0 ? (void*)M.dGathered : (void*)send, (size_t)run.count * nSlots * 4, ncclFloat, 0, M.comms[r], M.kids[run.first]->stream);
+            if (e != ncclSuccess) { g_rccl.GroupEnd(); return fail(PT_ERR_HIP, std::string("ncclGather: ") + g_rccl.GetErrorString(e)); }
         }
         RCCL_TRY(g_rccl.GroupEnd());
-        HIP_TRY(hipSetDevice(M.devices[0]));
-    } else {
-        if (M.ev.empty()) { M.ev.assign(M.n, nullptr); for (int i = 0; i < M.n; i++) { HIP_TRY(hipSetDevice(M.devices[i])); HIP_TRY(hipEventCreateWithFlags(&M.ev[i], hipEventDisableTiming)); } }
-        for (int i = 0; i < M.n; i++) {
-            HIP_TRY(hipSetDevice(M.devices[i]));
-            HIP_TRY(hipEventRecord(M.ev[i], M.kids[i]->stream));
-        }
-        HIP_TRY(hipSetDevice(M.devices[0]));
-        for (int i = 0; i < M.n; i++) {
-            HIP_TRY(hipStreamWaitEvent(root->stream, M.ev[i], 0));
-            HIP_TRY(hipMemcpyAsync(M.dGathered + (size_t)i * nSlots, img[i], nSlots * 16, hipMemcpyDeviceToDevice, root->stream));
-        }
-        // the shards must not rotate their image rings past this image before the copies have read it
-        HIP_TRY(hipEventRecord(M.ev[0], root->stream));
-        for (int i = 1; i < M.n; i++) { HIP_TRY(hipSetDevice(M.devices[i])); HIP_TRY(hipStreamWaitEvent(M.kids[i]->stream, M.ev[0], 0)); }
-        HIP_TRY(hipSetDevice(M.devices[0]));
     }
+    HIP_TRY(hipSetDevice(M.devices[0]));
+    M.gathers++;
+    if (M.shardTotal != M.n) { *out = M.dGathered; return 0; }     // a part of the image: the host layer gathers the blocks of all processes
     hipLaunchKernelGGL(k_unshard, dim3((unsigned)((total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, root->stream, (const float4*)M.dGathered, M.dAllMaps, (int)nSlots, M.n, M.dFull);
     HIP_TRY(hipGetLastError());
-    M.gathers++;
-    *fullOut = M.dFull;
+    *out = M.dFull;
     return 0;
 }
 

@@ -20,6 +20,8 @@ public final class PtNative {
     /** ONE context for several GPUs of the node (pt_create_multi): what dispatch.java's single thread drives; every method below
      *  works on it, readFrame / readDisplay / gatherImage perform the one RCCL gather of an image */
     public static native long createMulti(int[] devices, int width, int height);
+    /** the same for a part of the image: the streams are tile shards firstShard.. of totalShards (one JVM per GPU; pt_create_multi_part) */
+    public static native long createMultiPart(int[] devices, int width, int height, int firstShard, int totalShards);
     public static native void destroy(long ctx);
     /** glBufferData(GL_SHADER_STORAGE_BUFFER, buf) + glBindBufferBase(binding): copy at call time */
     public static native void setBuffer(long ctx, int binding, Buffer directBuffer, long bytes);
@@ -44,6 +46,8 @@ public final class PtNative {
     public static native long gatherImage(long ctx, int age);
     /** glFinish() */
     public static native void synchronize(long ctx);
+    /** wait for what is enqueued on the context's streams (a gather, an un-tiling) without completing batches in flight (pt_stream_wait) */
+    public static native void streamWait(long ctx);
     /** glReadPixels of the RGBA32F FRAME image into a direct FloatBuffer of width*height*4 floats */
     public static native void readFrame(long ctx, Buffer rgbaOut);
     /** functions.screenshot's pixels (dispatch.java:804-833): width*height*3 bytes, top row first; javaBytes = keep its signed-byte packing */

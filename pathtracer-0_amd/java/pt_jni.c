@@ -34,6 +34,16 @@ JNIEXPORT jlong JNICALL Java_Main_PtNative_createMulti(JNIEnv* env, jclass c, ji
     if (rc != PT_OK) { throw_rt(env, "pt_create_multi"); return 0; }
     return (jlong)(intptr_t)ctx;
 }
+JNIEXPORT jlong JNICALL Java_Main_PtNative_createMultiPart(JNIEnv* env, jclass c, jintArray devices, jint w, jint h, jint first, jint total) {
+    pt_ctx* ctx = NULL;
+    jsize n = (*env)->GetArrayLength(env, devices);
+    jint* d = (*env)->GetIntArrayElements(env, devices, NULL);
+    int rc = pt_create_multi_part(&ctx, (const int*)d, (int)n, w, h, first, total);
+    (*env)->ReleaseIntArrayElements(env, devices, d, JNI_ABORT);
+    if (rc != PT_OK) { throw_rt(env, "pt_create_multi_part"); return 0; }
+    return (jlong)(intptr_t)ctx;
+}
+JNIEXPORT void JNICALL Java_Main_PtNative_streamWait(JNIEnv* env, jclass c, jlong h) { CHECK(pt_stream_wait(CTX(h)), "pt_stream_wait"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_destroy(JNIEnv* env, jclass c, jlong h) { pt_destroy(CTX(h)); }
 JNIEXPORT void JNICALL Java_Main_PtNative_setBuffer(JNIEnv* env, jclass c, jlong h, jint binding, jobject buf, jlong bytes) {
     void* p = (*env)->GetDirectBufferAddress(env, buf);

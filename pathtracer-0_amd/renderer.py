@@ -32,6 +32,7 @@ def lib():
         L.pt_last_error.restype = C.c_char_p
         L.pt_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
         L.pt_create_multi.argtypes = [C.POINTER(vp), C.POINTER(ci), ci, ci, ci]
+        L.pt_create_multi_part.argtypes = [C.POINTER(vp), C.POINTER(ci), ci, ci, ci, ci, ci]
         L.pt_gather_image.argtypes = [vp, ci, C.POINTER(vp)]
         L.pt_destroy.argtypes = [vp]
         L.pt_set_buffer.argtypes = [vp, ci, vp, sz]
@@ -44,6 +45,7 @@ def lib():
         L.pt_finish_image.argtypes = [vp, ci]
         L.pt_image_device.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(sz)]
         L.pt_synchronize.argtypes = [vp]
+        L.pt_stream_wait.argtypes = [vp]
         L.pt_read_frame.argtypes = [vp, vp]
         L.pt_read_display.argtypes = [vp, ci, ci, vp]
         L.pt_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -90,18 +92,21 @@ def shard_map(W, H, rank, count):
 
 
 class Renderer:
-    """One render context.  `devices=[...]`: ONE context for several GPUs (pt_create_multi): the tile shards, the per-device host
-    threads and the RCCL gather of every image live inside the library; a device listed twice rehearses the sharding on one GPU."""
+    """One render context.  `devices=[...]`: ONE context made of several wavefront streams (pt_create_multi): one entry per stream —
+    several GPUs ([0, 1, ...]), several independent streams on one GPU ([0, 0]: their kernels overlap, 9-24 % faster than one), or both
+    ([0, 0, 1, 1]); the tile shards, the per-stream host threads and the gather of every image live inside the library.
+    first_shard / total_shards: the group renders only shards first_shard.. of total_shards (one process per GPU; pt_create_multi_part)."""
 
-    def __init__(self, W, H, device=0, shard_rank=0, shard_count=1, devices=None):
+    def __init__(self, W, H, device=0, shard_rank=0, shard_count=1, devices=None, first_shard=0, total_shards=None):
         self._L = lib()
         self._h = C.c_void_p()
         self.W, self.H, self.shard_rank, self.shard_count = W, H, shard_rank, shard_count
         self.devices = None if devices is None else [int(d) for d in devices]
         if self.devices is not None:
-            assert shard_count == 1 and shard_rank == 0, "a multi-GPU context shards by itself"
+            assert shard_count == 1 and shard_rank == 0, "a multi-stream context shards by itself"
             arr = (C.c_int * len(self.devices))(*self.devices)
-            _check(self._L.pt_create_multi(C.byref(self._h), arr, len(self.devices), W, H))
+            self.first_shard, self.total_shards = int(first_shard), int(total_shards if total_shards is not None else len(self.devices))
+            _check(self._L.pt_create_multi_part(C.byref(self._h), arr, len(self.devices), W, H, self.first_shard, self.total_shards))
         else:
             _check(self._L.pt_create(C.byref(self._h), device, W, H, shard_rank, shard_count))
 
@@ -170,6 +175,10 @@ class Renderer:
 
     def synchronize(self):
         _check(self._L.pt_synchronize(self._h))
+
+    def stream_wait(self):
+        """wait for what is enqueued on the context's stream(s) (gather, un-tiling, accumulation) without completing batches in flight"""
+        _check(self._L.pt_stream_wait(self._h))
 
     def read_frame(self, out=None):
         if out is None:

@@ -37,13 +37,17 @@ class Unsharder:
     (pt_unshard / k_unshard on the renderer's stream, the same one the multi-GPU context runs after its ncclGather); the torch
     index form is what the CPU (gloo) tests exercise."""
 
-    def __init__(self, W, H, world, shard_map_fn, device, renderer=None):
+    def __init__(self, W, H, world, shard_map_fn, device, renderer=None, ranks=None, sync_before_unshard=False):
+        """world: tile shards of the image; ranks: processes that gather (default: one shard per process); sync_before_unshard: the
+        renderer's streams are not torch's (a multi-stream context), so the collective's result is waited for before the un-tiling kernel"""
         maps = torch.from_numpy(all_maps(W, H, world, shard_map_fn).astype(np.int64))
-        self.W, self.H, self.world = W, H, world
+        self.W, self.H, self.shards = W, H, world
+        self.world = world if ranks is None else ranks
+        self.sync = sync_before_unshard
         self.renderer = renderer if torch.device(device).type == "cuda" else None
         self.src = torch.nonzero(maps >= 0).squeeze(1).to(device)          # packed slots that carry a pixel
         self.dst = maps[maps >= 0].to(device)                               # their global pixel indices
-        self.identity = world == 1 and bool((self.src.cpu() == self.dst.cpu()).all())
+        self.identity = world == 1 and bool((self.src.cpu() == self.dst.cpu()).all())      # one shard: the packed accumulator is the image
         self._full = None
 
     def __call__(self, gathered):
@@ -52,7 +56,9 @@ class Unsharder:
         if self.renderer is not None and gathered.is_cuda:
             if self._full is None:
                 self._full = torch.empty((self.H * self.W, 4), dtype=gathered.dtype, device=gathered.device)
-            self.renderer.unshard(gathered.data_ptr(), self._full.data_ptr())      # stream-ordered on the renderer's stream (= torch's current one)
+            if self.sync:
+                torch.cuda.current_stream(gathered.device).synchronize()
+            self.renderer.unshard(gathered.data_ptr(), self._full.data_ptr())      # stream-ordered on the renderer's stream
             return self._full.reshape(self.H, self.W, 4)
         full = torch.empty((self.H * self.W, 4), dtype=gathered.dtype, device=gathered.device)
         full.index_copy_(0, self.dst, gathered.index_select(0, self.src))

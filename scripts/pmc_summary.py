@@ -49,7 +49,8 @@ def main(d, cfg, fps):
         sres = plain["config"]["spp_per_step"] // fps
         seg = W * H * sres * fps * 2 * S
         out.update({"segments_per_sample": S, "segments_in_a_pass": seg, "plain_run": {"value": plain["value"], "ms_per_step": plain["ms_per_step"],
-                    "extend_avg_launch_ms": rf.get("avg_launch_ms"), "shade_avg_launch_ms": rf.get("shade_avg_launch_ms"), "extend_launches": rf.get("launches"),
+                    "extend_avg_launch_ms": rf.get("avg_launch_ms"), "shade_avg_launch_ms": (rf.get("shade") or {}).get("avg_launch_ms", rf.get("shade_avg_launch_ms")),
+                    "extend_launches": rf.get("launches"),
                     "per_segment": rf.get("per_segment")}})
     else:
         seg = None

@@ -1,0 +1,46 @@
+#!/bin/bash
+# round-2 measurement pass: counter summaries (final kernels), kernel-trace stats, the bench lines, shard rehearsals
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r02f
+mkdir -p $O
+cd $R
+# 1. counters per configuration -> profiles/pmc_<cfg>.json (bench.py's roofline block reads them)
+FPS=32 bash scripts/pmc_all.sh r02f/pmc_C3 C3 > $O/pmc_C3.log 2>&1; cp $O/pmc_C3/summary.json profiles/pmc_C3.json; echo "pmc C3 done"
+FPS=16 bash scripts/pmc_all.sh r02f/pmc_C4 C4 > $O/pmc_C4.log 2>&1; cp $O/pmc_C4/summary.json profiles/pmc_C4.json; echo "pmc C4 done"
+FPS=4 bash scripts/pmc_all.sh r02f/pmc_C5 C5 > $O/pmc_C5.log 2>&1; cp $O/pmc_C5/summary.json profiles/pmc_C5.json; echo "pmc C5 done"
+FPS=8 bash scripts/pmc_all.sh r02f/pmc_C2 C2 > $O/pmc_C2.log 2>&1; cp $O/pmc_C2/summary.json profiles/pmc_C2.json; echo "pmc C2 done"
+# 2. the driver's command
+timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_c3.json 2> $O/bench_default_c3.err; echo "bench rc=$?"
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c3_untimed_kernels.json 2>/dev/null
+for cfg in C2 C4 C5; do timeout -k 10 600 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; done
+# 3. kernel trace + stats of the bench command (its average k_extend_persist duration must agree with the HIP-event figure)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_trace.json 2> $O/bench_trace.err )
+python3 - <<PY
+import csv, glob, json
+for f in glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True):
+    print("name,calls,total_ms,avg_us,percent,min_us,max_us")
+    for row in csv.DictReader(open(f)):
+        n=row["Name"]; i=n.find("k_"); n=n[i:i+40] if i>=0 else n[:40]
+        print(f"{n},{row['Calls']},{float(row['TotalDurationNs'])/1e6:.3f},{float(row['AverageNs'])/1e3:.2f},{float(row['Percentage']):.3f},{float(row['MinNs'])/1e3:.2f},{float(row['MaxNs'])/1e3:.2f}")
+for l in open("$O/bench_trace.json"):
+    if l.startswith("{"):
+        d=json.loads(l); print("bench line of the traced run:", json.dumps({k:d[k] for k in ("value","ms_per_step","steps")}), json.dumps({k:d["roofline"][k] for k in ("avg_launch_ms","launches","frac")}), "shade avg", d["roofline"]["shade"]["avg_launch_ms"])
+PY
+rm -rf $O/trace
+# 4. tile-shard rehearsals (one shard of N alone on this GPU) and the multi-GPU context with two shards on this GPU
+for n in 1 2 4 8; do timeout -k 10 300 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --rehearse-shard 0 $n 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('shard 0 of $n ->', d['value'], 'Ms/s  ms/step', d['ms_per_step'])
+"; done | tee $O/rehearsals.txt
+timeout -k 10 300 python3 bench.py --gpus 2 --devices 0,0 --steps 4 --warmup 1 > $O/bench_multi_0_0.json 2> $O/bench_multi_0_0.err; echo "multi rc=$?"
+timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 4 --warmup 1 > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err; echo "torchrun rc=$?"
+python3 - <<PY
+import json,glob
+for f in sorted(glob.glob("$O/bench_*.json")):
+    for l in open(f):
+        if l.startswith("{"):
+            d=json.loads(l); r=d.get("roofline",{})
+            print(f.split("/")[-1], d["value"], "Ms/s", d["ms_per_step"], "ms/step", "frac", r.get("frac"), "hbm", (r.get("hbm") or {}).get("frac"), "shade", (r.get("shade") or {}).get("frac"), "parity", d.get("parity"))
+PY

@@ -32,6 +32,8 @@ static int (*pt_render_)(pt_ctx*, int, int);
 static int (*pt_read_frame_)(pt_ctx*, float*);
 /* the rest of the boundary (every non-debug symbol of pt_api.h is driven below) */
 static int (*pt_create_multi_)(pt_ctx**, const int*, int, int, int);
+static int (*pt_create_multi_part_)(pt_ctx**, const int*, int, int, int, int, int);
+static int (*pt_stream_wait_)(pt_ctx*);
 static int (*pt_render_batch_)(pt_ctx*, int, int, const int32_t*);
 static int (*pt_render_batch_async_)(pt_ctx*, int, int, const int32_t*);
 static int (*pt_next_image_)(pt_ctx*);
@@ -86,7 +88,7 @@ int main(int argc, char** argv) {
     SYM(host, pts_add_object_text) SYM(host, pts_add_ellipsoid) SYM(host, pts_pack) SYM(host, pts_get_buffer)
     SYM(hip, pt_create) SYM(hip, pt_destroy) SYM(hip, pt_last_error) SYM(hip, pt_set_buffer) SYM(hip, pt_set_texture) SYM(hip, pt_reset_frame)
     SYM(hip, pt_render) SYM(hip, pt_read_frame)
-    SYM(hip, pt_create_multi) SYM(hip, pt_render_batch) SYM(hip, pt_render_batch_async) SYM(hip, pt_next_image) SYM(hip, pt_finish_image) SYM(hip, pt_image_device)
+    SYM(hip, pt_create_multi) SYM(hip, pt_create_multi_part) SYM(hip, pt_stream_wait) SYM(hip, pt_render_batch) SYM(hip, pt_render_batch_async) SYM(hip, pt_next_image) SYM(hip, pt_finish_image) SYM(hip, pt_image_device)
     SYM(hip, pt_gather_image) SYM(hip, pt_synchronize) SYM(hip, pt_read_display) SYM(hip, pt_frame_device) SYM(hip, pt_shard_slots) SYM(hip, pt_shard_map)
     SYM(hip, pt_unshard) SYM(hip, pt_set_stream) SYM(hip, pt_build_bvh) SYM(hip, pt_get_counters) SYM(hip, pt_reset_counters)
     void* rt = dlopen("libamdhip64.so", RTLD_NOW);
@@ -171,6 +173,19 @@ int main(int argc, char** argv) {
     REQUIRE(pt_gather_image_(multi, 0, &whole) == 0 && whole != NULL && pt_synchronize_(multi) == 0, "pt_gather_image on the multi-GPU context");
     REQUIRE(hipMemcpy_(other, whole, fbytes, 2) == 0 && memcmp(frame, other, fbytes) == 0, "gathered image == one GPU");
     pt_destroy_(multi);
+    /* two groups of two streams each hold shards 0-1 and 2-3 of 4 (one process per GPU, two streams per GPU): each gathers its packed
+     * block, the blocks side by side are what the host layer's collective delivers, pt_unshard rebuilds the image */
+    { pt_ctx* part[2] = {NULL, NULL}; size_t s4 = 0; void *g4 = NULL, *f4 = NULL;
+      REQUIRE(pt_shard_slots_(W, H, 4, &s4) == 0 && hipMalloc_(&g4, 4 * s4 * 16) == 0 && hipMalloc_(&f4, fbytes) == 0, "buffers for four shards");
+      for (int p = 0; p < 2; p++) {
+          void* block = NULL;
+          REQUIRE(pt_create_multi_part_(&part[p], devs, 2, W, H, 2 * p, 4) == 0 && upload(part[p], sc, W, H) == 0 && pt_reset_frame_(part[p]) == 0 &&
+                  pt_render_batch_(part[p], 1, frames, seeds) == 0 && pt_gather_image_(part[p], 0, &block) == 0 && block && pt_stream_wait_(part[p]) == 0, "pt_create_multi_part");
+          REQUIRE(hipMemcpy_((char*)g4 + (size_t)p * 2 * s4 * 16, block, 2 * s4 * 16, 3) == 0, "copy of a packed block");
+      }
+      REQUIRE(pt_unshard_(part[0], g4, f4) == 0 && pt_stream_wait_(part[0]) == 0 && hipMemcpy_(other, f4, fbytes, 2) == 0, "pt_unshard of four shards");
+      REQUIRE(memcmp(frame, other, fbytes) == 0, "two part groups + pt_unshard == the frame");
+      pt_destroy_(part[0]); pt_destroy_(part[1]); hipFree_(g4); hipFree_(f4); }
     /* the reference's BVH builder on the GPU: two triangles -> a root and two leaves */
     { const double tri9[18] = {0, 0, 0, 1, 1, 0, 1.0 / 3, 1.0 / 3, 0, 2, 0, 0, 3, 1, 0, 7.0 / 3, 1.0 / 3, 0};
       int32_t nn = 0, links[8], leaf[8], lt[2], depth = 0; double bounds[24];

@@ -137,14 +137,14 @@ def test_jni_shim_covers_the_boundary():
     java = open(os.path.join(ROOT, "pathtracer-0_amd", "java", "Main", "PtNative.java")).read()
     jni = open(os.path.join(ROOT, "pathtracer-0_amd", "java", "pt_jni.c")).read()
     natives = re.findall(r"public static native [\w\[\]]+ (\w+)\(", java)
-    assert len(natives) >= 19
+    assert len(natives) >= 21
     for n in natives:
         assert f"Java_Main_PtNative_{n}(" in jni, n
     assert len(re.findall(r"JNIEXPORT", jni)) == len(natives)
     api = set(declared("pt_api.h"))
     called = set(re.findall(r"\b(pt_[a-z_]+)\(", jni))
     assert called <= api, called - api
-    for need in ("pt_create", "pt_create_multi", "pt_destroy", "pt_set_buffer", "pt_set_texture", "pt_reset_frame", "pt_render", "pt_render_batch", "pt_render_batch_async",
+    for need in ("pt_create", "pt_create_multi", "pt_create_multi_part", "pt_stream_wait", "pt_destroy", "pt_set_buffer", "pt_set_texture", "pt_reset_frame", "pt_render", "pt_render_batch", "pt_render_batch_async",
                  "pt_next_image", "pt_finish_image", "pt_image_device", "pt_gather_image", "pt_synchronize", "pt_read_frame", "pt_read_display", "pt_get_counters",
                  "pt_reset_counters", "pt_last_error"):
         assert need in called, need

@@ -1,10 +1,13 @@
-"""GPU: the multi-GPU context behind the C ABI (pt_create_multi / pt_gather_image, csrc/hip/pt_multi.hpp) and bench.py's launch forms.
+"""GPU: the multi-stream context behind the C ABI (pt_create_multi / pt_create_multi_part / pt_gather_image, csrc/hip/pt_multi.hpp) and
+bench.py's launch forms.
 
 A one-GPU box cannot run two RCCL ranks (RCCL refuses two ranks on one device), so:
-  * devices=[0, 0] / [0, 0, 0]: several shards on one GPU — the whole group machinery (one host thread per shard, replicated
-    scene, image ring, shard maps, padding, un-tiling kernel) with the gather by device copies;
-  * devices=[0]: a group of one — dlopen(librccl), ncclCommInitAll, ncclGather in a group call, un-tiling: the RCCL call path.
-Everything must be bit-identical to the plain one-GPU context (K10, frag.glsl:886,896: the RNG is keyed on the global pixel).
+  * devices=[0, 0] / [0, 0, 0] ...: several independent streams on one GPU (the production form: two streams per GPU) — one host thread
+    per stream, replicated scene, image ring, shard maps, padding, device-copy gather, un-tiling kernel;
+  * the same with PT_MULTI_FORCE_RCCL=1: the RCCL call path of the several-GPU form on one device — dlopen(librccl), ncclCommInitAll,
+    the streams' accumulators staged side by side, ONE ncclGather of the block in a group call, un-tiling;
+  * pt_create_multi_part: two groups holding shards 0-1 and 2-3 of 4 (one process per GPU, two streams each) + pt_unshard.
+Everything must be bit-identical to the plain one-stream context (K10, frag.glsl:886,896: the RNG is keyed on the global pixel).
 """
 import json
 import os
@@ -55,6 +58,58 @@ def test_multi_context_equals_single(pt, renderer_mod, devices, W, H):
     r1.close()
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_multi_context_through_rccl(pt, renderer_mod, devices, monkeypatch):
+    """the gather of the several-GPU form (staging block per device + ONE ncclGather + un-tiling), forced onto the one device of this box"""
+    monkeypatch.setenv("PT_MULTI_FORCE_RCCL", "1")
+    W, H = 100, 37
+    wl = pt.scenes.build("C2", W, H)
+    seeds = _seeds(pt, 2)
+    rm = renderer_mod.Renderer(W, H, devices=devices)
+    rm.load_workload(wl); rm.reset_frame(); rm.render_batch(1, seeds)
+    got = rm.read_frame().copy()
+    rm.next_image(); rm.render_batch_async(1, seeds[:1]); rm.render_batch_async(2, seeds[1:])
+    again = rm.read_frame().copy()                              # a second gather through the same communicator
+    rm.close()
+    monkeypatch.delenv("PT_MULTI_FORCE_RCCL")
+    r1 = renderer_mod.Renderer(W, H)
+    r1.load_workload(wl); r1.reset_frame(); r1.render_batch(1, seeds)
+    ref = r1.read_frame(); r1.close()
+    assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(again, ref, equal_nan=True)
+
+
+def test_part_groups_and_unshard(pt, renderer_mod):
+    """one process per GPU with two streams each, here both "processes" on GPU 0: groups of shards 0-1 and 2-3 of 4; each packs its block
+    (pt_gather_image), the blocks side by side are what the processes' collective delivers, pt_unshard rebuilds the image"""
+    import torch
+    from pathtracer_0_amd import shard
+    W, H = 160, 90
+    wl = pt.scenes.build("C3", W, H)
+    seeds = _seeds(pt, 3)
+    ns = renderer_mod.shard_slots(W, H, 4)
+    parts, blocks = [], []
+    acc = np.zeros((H, W, 4), np.float32)
+    for p in range(2):
+        g = renderer_mod.Renderer(W, H, devices=[0, 0], first_shard=2 * p, total_shards=4)
+        g.load_workload(wl); g.reset_frame(); g.render_batch(1, seeds)
+        blk = torch.as_tensor(shard._DevArray(g.gather_image(0), (2 * ns, 4)), device="cuda:0")
+        g.stream_wait()
+        blocks.append(blk.clone()); parts.append(g)
+        g.read_frame(acc)                                        # a part group writes only its own pixels
+    gathered = torch.cat(blocks).contiguous()
+    full = torch.empty((H * W, 4), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    parts[0].unshard(gathered.data_ptr(), full.data_ptr())
+    parts[0].stream_wait()
+    got = full.cpu().numpy().reshape(H, W, 4)
+    for g in parts:
+        g.close()
+    r1 = renderer_mod.Renderer(W, H)
+    r1.load_workload(wl); r1.reset_frame(); r1.render_batch(1, seeds)
+    ref = r1.read_frame(); r1.close()
+    assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(acc, ref, equal_nan=True)
+
+
 def test_multi_context_overlapped_images(pt, renderer_mod):
     """bench.py's schedule on the group: a new image per step (pt_next_image), asynchronous batches, each image gathered LAG steps later"""
     import torch
@@ -90,6 +145,9 @@ def test_multi_context_errors(pt, renderer_mod):
     with pytest.raises(renderer_mod.PtError) as e:
         renderer_mod.Renderer(64, 48, devices=[0, 99])       # no such device
     assert e.value.code == -2
+    with pytest.raises(renderer_mod.PtError) as e:
+        renderer_mod.Renderer(64, 48, devices=[0, 0], first_shard=3, total_shards=4)       # shards 3 and 4 of 4
+    assert e.value.code == -1
     rm = renderer_mod.Renderer(64, 48, devices=[0, 0])
     with pytest.raises(renderer_mod.PtError):
         rm.render(1, 5)                                       # no scene yet: the shard's error comes back through the group, with its device
@@ -111,17 +169,21 @@ def _bench(*flags, env=None, launcher=()):
     return json.loads(lines[0])
 
 
-def test_bench_runs_unaided_with_several_shards():
-    """`python bench.py --gpus 2` started plainly (no launcher): the single-process multi-GPU context; here both shards on GPU 0"""
-    d = _bench("--gpus", "2", "--devices", "0,0")
-    assert d["parity"]["gathered_image_bit_identical_to_one_gpu_render"] is True
-    assert d["value"] > 0 and "rehearsal" in d
-    assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0
+def test_bench_default_is_two_streams_on_one_gpu():
+    """`python bench.py` (the driver's N = 1 command): one GPU, two independent wavefront streams behind one context, checked against the oracle"""
+    d = _bench("--gpus", "1")
+    assert d["n_gpus"] == 1 and "2 independent wavefront stream(s) per GPU" in d["config"]["multi_gpu"]
+    assert d["parity"]["bit_identical"] is True and d["cpu_baseline"]["value"] > 0
+    r = d["roofline"]
+    assert 0 < r["frac"] <= 1 and 0 < r["chip"]["valu_issue"]["frac"] <= 1 and 0 < r["chip"]["hbm"]["frac"] <= 1 and r["chip"]["streams_per_gpu"] == 2
 
 
-def test_bench_group_of_one_goes_through_rccl():
-    d = _bench("--gpus", "1", "--devices", "0")
-    assert d["n_gpus"] == 1 and d["parity"]["gathered_image_bit_identical_to_one_gpu_render"] is True and "RCCL" in d["config"]["multi_gpu"]
+def test_bench_runs_unaided_with_several_gpus_worth_of_streams():
+    """`python bench.py --gpus N` started plainly (no launcher) builds ONE context for all streams; here four streams on GPU 0, gathered through RCCL"""
+    d = _bench("--gpus", "1", "--devices", "0,0,0,0", "--no-cpu-baseline", env={"PT_MULTI_FORCE_RCCL": "1"})
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    d = _bench("--gpus", "1", "--streams", "1")
+    assert d["parity"]["bit_identical"] is True and "one stream" in d["config"]["multi_gpu"]
 
 
 def test_bench_under_torch_distributed_run_nccl():
@@ -130,3 +192,27 @@ def test_bench_under_torch_distributed_run_nccl():
     d = _bench("--gpus", "1", launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533"))
     assert d["n_gpus"] == 1 and "torch.distributed" in d["config"]["multi_gpu"]
     assert d["parity"]["gathered_image_bit_identical_to_one_gpu_render"] is True
+
+
+def test_part_group_path_of_a_two_rank_run():
+    """what rank 0 of `torch.distributed.run --nproc-per-node 2` does, without the second GPU: `--dist` at world 1 is covered above; here the
+    packed-block path itself — a part group (shards 0-1 of 4), its block gathered by torch.distributed (nccl, world 1) — in a child process"""
+    code = (
+        "import os,sys,numpy as np,torch,torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import ptimport; pt=ptimport.load()\n"
+        "from pathtracer_0_amd import renderer, scenes, shard\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29547', RANK='0', WORLD_SIZE='1')\n"
+        "dev=torch.device('cuda',0); torch.cuda.set_device(0); dist.init_process_group('nccl', device_id=dev)\n"
+        "W,H=128,72; wl=scenes.build('C2',W,H)\n"
+        "g=renderer.Renderer(W,H,devices=[0,0],first_shard=0,total_shards=4); g.load_workload(wl); g.reset_frame(); g.render_batch(1,[5,6])\n"
+        "ns=renderer.shard_slots(W,H,4)\n"
+        "blk=torch.as_tensor(shard._DevArray(g.gather_image(0),(2*ns,4)),device=dev); g.stream_wait()\n"
+        "out=torch.empty((1,2*ns,4),device=dev); dist.gather(blk, list(out.unbind(0)), dst=0); torch.cuda.synchronize()\n"
+        "r1=renderer.Renderer(W,H); r1.load_workload(wl); r1.reset_frame(); r1.render_batch(1,[5,6]); ref=r1.read_frame().reshape(-1,4)\n"
+        "m=np.concatenate([renderer.shard_map(W,H,s,4) for s in (0,1)])\n"
+        "got=out[0].cpu().numpy()\n"
+        "assert np.array_equal(got[m>=0], ref[m[m>=0]], equal_nan=True)\n"
+        "g.close(); r1.close(); dist.destroy_process_group(); print('PART_OK')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "PART_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
