@@ -29,6 +29,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The streams of a GPU must land on different hardware queues to overlap.  Left to its default the HIP runtime put both streams of a
+# process that also hosts torch's and RCCL's streams on ONE queue (kernel concurrency 1.1 instead of 2.0, profiles/r02_i_*); with the
+# variable set — read once, when the process initialises HIP — they are dealt round-robin.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 try:
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]      # "Msamples/sec (whole node) at 1920x1080x8-bounce; per-pixel RMSE vs ref"
@@ -90,7 +94,8 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
                     "traffic": round(ke.get("hbm_bytes_per_segment", 0.0) * seg_per_launch) if "hbm_bytes_per_segment" in ke else None,
                     "valu_insts_per_segment": ke["valu_per_segment"], "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"),
                     "wait_share": ke.get("wait_share"), "issue_stall_share": ke.get("issue_stall_share"), "counters_from": prof_name,
-                    "note": "the intersect kernel is bound by VALU issue and the latency of dependent node fetches, not by bytes: achieved = SQ_INSTS_VALU per segment "
+                    "note": "with several streams per GPU a launch shares the chip with the other streams' launches (see chip.kernel_concurrency): these per-launch figures are what "
+                            "ONE stream's kernel reaches, chip.* what the chip reaches.  The intersect kernel is bound by VALU issue and the latency of dependent node fetches, not by bytes: achieved = SQ_INSTS_VALU per segment "
                             "(committed rocprofv3 summary) x segments per launch / mean launch time (live HIP events); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per "
                             "wave64 instruction; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"})
         if "hbm_bytes_per_segment" in ke:
@@ -179,7 +184,10 @@ def main():
         n_gpus, shards = world, world * K
     else:
         shard_rank, shard_count = (0, 1) if not args.rehearse_shard else tuple(args.rehearse_shard)
-        r = renderer.Renderer(W, H, device=local_rank, shard_rank=shard_rank, shard_count=shard_count)
+        if args.rehearse_shard and K > 1:           # one GPU's part of a shard_count-GPU run: its K streams = shards rank*K.. of shard_count*K
+            r = renderer.Renderer(W, H, devices=[local_rank] * K, first_shard=shard_rank * K, total_shards=shard_count * K)
+        else:
+            r = renderer.Renderer(W, H, device=local_rank, shard_rank=shard_rank, shard_count=shard_count)
         n_gpus, shards = 1, shard_count
     if args.path_slots:
         r.set_option("path_slots", args.path_slots)
@@ -208,7 +216,9 @@ def main():
         collect(0)                              # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
         torch.cuda.synchronize(dev)
     else:
-        if args.rehearse_shard:
+        if args.rehearse_shard and K > 1:
+            collect = lambda age: r.gather_image(age)                                             # noqa: E731  (the packed block, as a pointer)
+        elif args.rehearse_shard:
             collect = lambda age: (r.finish_image(age), shard.frame_tensor(r, dev, age))[1]      # noqa: E731
         else:
             collect = lambda age: torch.as_tensor(shard._DevArray(r.gather_image(age), (H, W, 4)), device=dev)      # noqa: E731
@@ -291,7 +301,8 @@ def main():
 
     samples = float(W) * H * spp_step * args.steps
     if args.rehearse_shard:
-        samples = float((renderer.shard_map(W, H, shard_rank, shard_count) >= 0).sum()) * spp_step * args.steps
+        own = [renderer.shard_map(W, H, shard_rank * K + k, shard_count * K) for k in range(K)] if K > 1 else [renderer.shard_map(W, H, shard_rank, shard_count)]
+        samples = float(sum((m >= 0).sum() for m in own)) * spp_step * args.steps
     value = samples / dt / 1e6
 
     per_gpu = f"{shards // max(n_gpus, 1)} independent wavefront stream(s) per GPU"
@@ -311,7 +322,7 @@ def main():
                    "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"], "multi_gpu": how},
     }
     if args.rehearse_shard:
-        out["rehearsal"] = f"shard {shard_rank} of {shard_count} alone on one GPU: value is THIS shard's rate, not a multi-GPU measurement"
+        out["rehearsal"] = f"GPU {shard_rank} of {shard_count} alone ({K} stream(s)): value is THIS GPU's share of the image at its own rate, not a multi-GPU measurement"
     if stats is not None:
         if dist_mode and world > 1:             # launches and device time of all ranks, like the multi-GPU context reports them
             acc = []

@@ -1485,6 +1485,9 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
 int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int width, int height, int first_shard, int total_shards) {
     if (!out || !devices || n_devices < 1 || n_devices > 64 || width < 1 || height < 1 || first_shard < 0 || total_shards < n_devices || first_shard + n_devices > total_shards)
         return fail(PT_ERR_ARG, "pt_create_multi: bad argument");
+    // streams that share a GPU overlap only on different hardware queues; the runtime deals them round-robin when this is set (it is read
+    // once, when the process initialises HIP: a host that has used HIP before this call sets it itself)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     for (int i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= nDev) return fail(PT_ERR_NO_DEVICE, "pt_create_multi: HIP device index out of range");

@@ -1,17 +1,18 @@
 #!/bin/bash
-# round-2 measurement pass: counter summaries (final kernels), kernel-trace stats, the bench lines, shard rehearsals
+# measurement pass (usage: measure_all.sh [out-tag]): counter summaries (final kernels), kernel-trace stats, the bench lines, shard rehearsals
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r02f
+O=$R/gpurun_out/${1:-measure}
 mkdir -p $O
 cd $R
 # 1. counters per configuration -> profiles/pmc_<cfg>.json (bench.py's roofline block reads them)
-FPS=32 bash scripts/pmc_all.sh r02f/pmc_C3 C3 > $O/pmc_C3.log 2>&1; cp $O/pmc_C3/summary.json profiles/pmc_C3.json; echo "pmc C3 done"
-FPS=16 bash scripts/pmc_all.sh r02f/pmc_C4 C4 > $O/pmc_C4.log 2>&1; cp $O/pmc_C4/summary.json profiles/pmc_C4.json; echo "pmc C4 done"
-FPS=4 bash scripts/pmc_all.sh r02f/pmc_C5 C5 > $O/pmc_C5.log 2>&1; cp $O/pmc_C5/summary.json profiles/pmc_C5.json; echo "pmc C5 done"
-FPS=8 bash scripts/pmc_all.sh r02f/pmc_C2 C2 > $O/pmc_C2.log 2>&1; cp $O/pmc_C2/summary.json profiles/pmc_C2.json; echo "pmc C2 done"
+FPS=32 bash scripts/pmc_all.sh ${1:-measure}/pmc_C3 C3 > $O/pmc_C3.log 2>&1; cp $O/pmc_C3/summary.json profiles/pmc_C3.json; echo "pmc C3 done"
+FPS=16 bash scripts/pmc_all.sh ${1:-measure}/pmc_C4 C4 > $O/pmc_C4.log 2>&1; cp $O/pmc_C4/summary.json profiles/pmc_C4.json; echo "pmc C4 done"
+FPS=4 bash scripts/pmc_all.sh ${1:-measure}/pmc_C5 C5 > $O/pmc_C5.log 2>&1; cp $O/pmc_C5/summary.json profiles/pmc_C5.json; echo "pmc C5 done"
+FPS=8 bash scripts/pmc_all.sh ${1:-measure}/pmc_C2 C2 > $O/pmc_C2.log 2>&1; cp $O/pmc_C2/summary.json profiles/pmc_C2.json; echo "pmc C2 done"
 # 2. the driver's command
 timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_c3.json 2> $O/bench_default_c3.err; echo "bench rc=$?"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c3_untimed_kernels.json 2>/dev/null
+timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 > $O/bench_c3_one_stream.json 2>/dev/null
 for cfg in C2 C4 C5; do timeout -k 10 600 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; done
 # 3. kernel trace + stats of the bench command (its average k_extend_persist duration must agree with the HIP-event figure)
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_trace.json 2> $O/bench_trace.err )
@@ -32,9 +33,14 @@ for n in 1 2 4 8; do timeout -k 10 300 python3 bench.py --steps 8 --warmup 2 --n
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
-        d=json.loads(l); print('shard 0 of $n ->', d['value'], 'Ms/s  ms/step', d['ms_per_step'])
+        d=json.loads(l); print('two streams: GPU 0 of $n ->', d['value'], 'Ms/s  ms/step', d['ms_per_step'])
 "; done | tee $O/rehearsals.txt
-timeout -k 10 300 python3 bench.py --gpus 2 --devices 0,0 --steps 4 --warmup 1 > $O/bench_multi_0_0.json 2> $O/bench_multi_0_0.err; echo "multi rc=$?"
+for n in 1 2 4 8; do timeout -k 10 300 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --streams 1 --rehearse-shard 0 $n 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('one stream: shard 0 of $n ->', d['value'], 'Ms/s  ms/step', d['ms_per_step'])
+"; done | tee -a $O/rehearsals.txt
 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 1 --steps 4 --warmup 1 > $O/bench_torchrun_n1.json 2> $O/bench_torchrun_n1.err; echo "torchrun rc=$?"
 python3 - <<PY
 import json,glob
