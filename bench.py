@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="independent wavefront streams per GPU (each a tile shard with its own path pool and HIP stream)")
     ap.add_argument("--devices", default=None, help="single-process multi-GPU context on these HIP devices, e.g. 0,1,2,3 (default 0..N-1); a device listed "
                                                     "twice (0,0) rehearses the sharding on one GPU (gather by device copies: RCCL refuses duplicate devices)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: the process-per-GPU form with the collective on CPU tensors — "
+                    "rehearses every line of the N > 1 path where the ranks cannot have a GPU each (with PT_BENCH_ONE_GPU=1 all ranks use GPU 0)")
     ap.add_argument("--dist", action="store_true", help="take the torch.distributed path even at WORLD_SIZE 1 (exercises the RCCL gather of the process-per-GPU form on one GPU)")
     for name in ("lds-budget", "extend-mode", "extend-tpb", "extend-cache", "refill-min", "none-min", "extend-blocks-per-cu", "inner-keep", "bfs-nodes", "stack-mode"):
         ap.add_argument("--" + name, type=int, default=None)
@@ -143,6 +145,9 @@ def main():
     world = int(env_world) if env_world is not None else (1 if args.dist else args.gpus)
     rank = int(os.environ.get("RANK", "0")) if dist_mode else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if dist_mode else 0
+    if os.environ.get("PT_BENCH_ONE_GPU") == "1":
+        local_rank = 0                              # rehearsal on a one-GPU box: every rank renders on GPU 0
+    gloo = dist_mode and args.dist_backend == "gloo"
     if dist_mode and env_world is not None and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: torch.distributed.run --nproc-per-node must equal --gpus")
     K = max(1, args.streams)
@@ -163,7 +168,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         if env_world is None:
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-        dist.init_process_group("nccl", device_id=dev)
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if gloo else dev     # where the collectives' tensors live
 
     cfg = scenes.CONFIGS[args.config]
     W = args.width or cfg["W"]
@@ -212,6 +221,9 @@ def main():
         def collect(age):                       # the library completes the image and packs this rank's block, RCCL gathers the blocks
             packed = torch.as_tensor(shard._DevArray(r.gather_image(age), (n_block, 4)), device=dev)
             r.stream_wait()                     # the block was written on the library's stream; torch's collective runs on another
+            if gloo:                            # rehearsal: the same gather on CPU tensors, the gathered blocks go back to the GPU for pt_unshard
+                packed = packed.cpu()
+                unshard.to_device = dev
             return shard.gather_frame(packed, unshard, dst=0, force_collective=True)
         collect(0)                              # untimed: RCCL builds its communicator and rings on the first collective, whatever --warmup is
         torch.cuda.synchronize(dev)
@@ -269,7 +281,7 @@ def main():
         r.synchronize()
         stats = r.counters()
         if dist_mode and world > 1:             # whole-image totals
-            t = torch.tensor([float(stats[k]) for k in renderer.COUNTERS], dtype=torch.float64, device=dev)
+            t = torch.tensor([float(stats[k]) for k in renderer.COUNTERS], dtype=torch.float64, device=cdev)
             dist.all_reduce(t)
             stats = dict(zip(renderer.COUNTERS, [int(x) for x in t.tolist()]))
         r.set_option("count_stats", 0)
@@ -295,7 +307,7 @@ def main():
     dt = time.perf_counter() - t0
     r.set_timing(False)
     if dist_mode:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -310,7 +322,8 @@ def main():
         how = (f"ONE process, pt_create_multi on devices {devices} ({per_gpu}): " +
                ("device copies between the streams of a GPU, RCCL ncclGather across GPUs, un-tiling on device " if n_gpus > 1 else "device copies between the streams, un-tiling on device ") + str(devices[0]))
     elif dist_mode:
-        how = f"one process per GPU, {per_gpu} (pt_create_multi_part), torch.distributed nccl (= RCCL) dist.gather of the packed blocks on rank 0, pt_unshard there; world {world}"
+        how = (f"one process per GPU, {per_gpu} (pt_create_multi_part), torch.distributed {'nccl (= RCCL)' if not gloo else 'gloo (REHEARSAL on CPU tensors)'} "
+               f"dist.gather of the packed blocks on rank 0, pt_unshard there; world {world}")
     else:
         how = "one GPU, one stream, no collective"
     out = {
@@ -321,6 +334,8 @@ def main():
                                f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs, tile-sharded over {shards} shard(s) on {n_gpus} GPU(s), 1 framebuffer gather per step",
                    "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"], "multi_gpu": how},
     }
+    if gloo or os.environ.get("PT_BENCH_ONE_GPU") == "1":
+        out["rehearsal"] = "process-per-GPU form rehearsed with a gloo collective and/or all ranks on one GPU: not a scaling measurement"
     if args.rehearse_shard:
         out["rehearsal"] = f"GPU {shard_rank} of {shard_count} alone ({K} stream(s)): value is THIS GPU's share of the image at its own rate, not a multi-GPU measurement"
     if stats is not None:
@@ -329,7 +344,7 @@ def main():
             for k in ("extend", "shade"):
                 n_k, ms_k = r.kernel_time(k)
                 acc += [float(n_k), ms_k]
-            t = torch.tensor(acc, dtype=torch.float64, device=dev)
+            t = torch.tensor(acc, dtype=torch.float64, device=cdev)
             dist.all_reduce(t)
             tot = t.tolist()
             med = {k: r.kernel_time_median(k) for k in ("extend", "shade")}

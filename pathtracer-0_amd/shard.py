@@ -50,7 +50,11 @@ class Unsharder:
         self.identity = world == 1 and bool((self.src.cpu() == self.dst.cpu()).all())      # one shard: the packed accumulator is the image
         self._full = None
 
+    to_device = None        # rehearsals with a CPU collective: the gathered blocks go to this device for the library's un-tiling kernel
+
     def __call__(self, gathered):
+        if self.to_device is not None and not gathered.is_cuda:
+            gathered = gathered.to(self.to_device)
         if self.identity:
             return gathered[: self.W * self.H].reshape(self.H, self.W, 4)
         if self.renderer is not None and gathered.is_cuda:

@@ -194,6 +194,16 @@ def test_bench_under_torch_distributed_run_nccl():
     assert d["parity"]["gathered_image_bit_identical_to_one_gpu_render"] is True
 
 
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """every line of the driver's N = 2 run (`torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`: part groups of two streams per rank,
+    all-reduced statistics, gather of the packed blocks, pt_unshard of four shards on rank 0, barrier + max-over-ranks timing) except RCCL itself,
+    which cannot hold two ranks on one device: the collective runs over gloo on CPU copies, both ranks render on GPU 0"""
+    d = _bench("--gpus", "2", "--dist-backend", "gloo", env={"PT_BENCH_ONE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+               launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29551"))
+    assert d["n_gpus"] == 2 and d["parity"]["gathered_image_bit_identical_to_one_gpu_render"] is True and "rehearsal" in d
+    assert "4 shard(s)" in d["config"]["workload"] and d["roofline"]["chip"]["streams_per_gpu"] == 2
+
+
 def test_part_group_path_of_a_two_rank_run():
     """what rank 0 of `torch.distributed.run --nproc-per-node 2` does, without the second GPU: `--dist` at world 1 is covered above; here the
     packed-block path itself — a part group (shards 0-1 of 4), its block gathered by torch.distributed (nccl, world 1) — in a child process"""
