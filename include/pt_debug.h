@@ -10,7 +10,7 @@
 extern "C" {
 #endif
 
-/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: a fifth of a synchronous batch clamped to [2^20, 2^22]; 5/8 of the
+/* Tuning knobs: 0 = path slots in flight (default 0 = automatic: one per job of a synchronous batch within [2^20, 2^22]; 5/8 of the
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
  * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,

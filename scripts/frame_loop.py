@@ -15,7 +15,12 @@ from pathtracer_0_amd import renderer, scenes  # noqa: E402
 
 W, H, N = 1920, 1080, 64
 wl = scenes.build("C3", W, H)
-r = renderer.Renderer(W, H)
+# usage: frame_loop.py [streams] [path_slots]   (streams > 1: pt_create_multi with GPU 0 listed that many times)
+streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+r = renderer.Renderer(W, H, devices=[0] * streams) if streams > 1 else renderer.Renderer(W, H)
+if len(sys.argv) > 2 and int(sys.argv[2]):
+    r.set_option("path_slots", int(sys.argv[2]))
+print(f"streams {streams}, path slots {sys.argv[2] if len(sys.argv) > 2 else 'automatic'}")
 r.load_workload(wl)
 seeds = [scenes.frame_seed(f) for f in range(1, N + 1)]
 
