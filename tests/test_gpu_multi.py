@@ -141,6 +141,34 @@ def test_multi_context_overlapped_images(pt, renderer_mod):
     r1.close()
 
 
+def test_multi_stream_scheduler_paths(pt, oracle, renderer_mod):
+    """the frame-stream scheduler under a two-stream context: overlapped images, a Parameters upload and a camera move between asynchronous
+    batches (each ends the running streams of BOTH shards first), synchronous calls in between — against the oracle, frame by frame"""
+    W, H = 96, 54
+    wl = pt.scenes.build("C3", W, H)
+    wl2 = wl.with_params(SAMPLE_RES=4, MAX_BOUNCES=2)
+    moved = wl.buffers[0].copy(); moved[0] += 0.2
+    r = renderer_mod.Renderer(W, H, devices=[0, 0])
+    r.set_option("path_slots", 1024)                           # per stream: deep backlogs
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch_async(1, [11, 22, 33])
+    r.set_buffer(4, wl2.buffers[4]); r.render_batch_async(4, [44])
+    r.set_buffer(4, wl.buffers[4]); r.set_buffer(0, moved); r.render(5, 55)
+    r.render_batch_async(6, [66, 77])
+    got = r.read_frame().copy()
+    cnt_ok = r.counters()["iterations"] > 0
+    r.close()
+    sc = oracle.Scene.from_workload
+    ref = np.zeros((H, W, 4), np.float32)
+    oracle.render_frames(sc(wl), W, H, 1, 3, [11, 22, 33], frame=ref, nthreads=8)
+    oracle.render_frames(sc(wl2), W, H, 4, 1, [44], frame=ref, nthreads=8)
+    b = dict(wl.buffers); b[0] = moved
+    wl3 = pt.scenes.Workload(wl.name, W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    oracle.render_frames(sc(wl3), W, H, 5, 1, [55], frame=ref, nthreads=8)
+    oracle.render_frames(sc(wl3), W, H, 6, 2, [66, 77], frame=ref, nthreads=8)
+    assert cnt_ok and np.array_equal(got, ref, equal_nan=True)
+
+
 def test_multi_context_errors(pt, renderer_mod):
     with pytest.raises(renderer_mod.PtError) as e:
         renderer_mod.Renderer(64, 48, devices=[0, 99])       # no such device
