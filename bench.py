@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="independent wavefront streams per GPU (each a tile shard with its own path pool and HIP stream)")
     ap.add_argument("--devices", default=None, help="single-process multi-GPU context on these HIP devices, e.g. 0,1,2,3 (default 0..N-1); a device listed "
                                                     "twice (0,0) rehearses the sharding on one GPU (gather by device copies: RCCL refuses duplicate devices)")
+    ap.add_argument("--spawn", action="store_true", help="N > 1 started plainly: instead of ONE process driving all GPUs through pt_create_multi, start "
+                    "`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (before this process touches HIP) and relay its line")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: the process-per-GPU form with the collective on CPU tensors — "
                     "rehearses every line of the N > 1 path where the ranks cannot have a GPU each (with PT_BENCH_ONE_GPU=1 all ranks use GPU 0)")
     ap.add_argument("--dist", action="store_true", help="take the torch.distributed path even at WORLD_SIZE 1 (exercises the RCCL gather of the process-per-GPU form on one GPU)")
@@ -140,6 +142,13 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
 
 def main():
     args = parse()
+    if args.spawn and args.gpus > 1 and os.environ.get("WORLD_SIZE") is None:
+        import socket
+        import subprocess
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        child = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
+        raise SystemExit(subprocess.call(child))      # the child's rank 0 prints the JSON line on the inherited stdout
     env_world = os.environ.get("WORLD_SIZE")
     dist_mode = env_world is not None or args.dist          # one process per GPU under torch.distributed.run
     world = int(env_world) if env_world is not None else (1 if args.dist else args.gpus)

@@ -232,6 +232,12 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert "4 shard(s)" in d["config"]["workload"] and d["roofline"]["chip"]["streams_per_gpu"] == 2
 
 
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2 --spawn`, started plainly: the parent starts torch.distributed.run before touching HIP and relays the line"""
+    d = _bench("--gpus", "2", "--spawn", "--dist-backend", "gloo", env={"PT_BENCH_ONE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert d["n_gpus"] == 2 and d["parity"]["gathered_image_bit_identical_to_one_gpu_render"] is True
+
+
 def test_part_group_path_of_a_two_rank_run():
     """what rank 0 of `torch.distributed.run --nproc-per-node 2` does, without the second GPU: `--dist` at world 1 is covered above; here the
     packed-block path itself — a part group (shards 0-1 of 4), its block gathered by torch.distributed (nccl, world 1) — in a child process"""
