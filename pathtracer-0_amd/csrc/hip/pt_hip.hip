@@ -269,6 +269,9 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, State st, const u
 //   CUR_NONE  ray alive, BVH of the current object exhausted   |   CUR_IDLE  lane has no ray
 // (activity is folded into `cur` so that every wave-level vote is ONE v_cmp writing an SGPR pair)
 //   CUR_DONE  ray finished, its hit record still in the lane's registers (stored at the wave's next refill)
+// lanes set in a wave mask, as a 32-bit SCALAR: left to __popcll the compiler keeps the count 64 bits wide and compares two counts with
+// v_cmp_*_u64 (there is no 64-bit scalar ordered compare) — six vector instructions per outer trip of the intersect kernel
+__device__ __forceinline__ int wavePop(unsigned long long m) { int n; asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc"); return n; }
 constexpr int CUR_NONE = 0x7ffffffd;
 constexpr int CUR_DONE = 0x7ffffffe;
 constexpr int CUR_IDLE = 0x7fffffff;
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
     for (;;) {
         // ---- refill idle lanes from the wave's range
         unsigned long long idle = __ballot(cur >= CUR_DONE);                // lanes without a ray in flight
-        int nIdle = __popcll(idle);
+        int nIdle = wavePop(idle);
         PS(4, 64 - nIdle);
         if (pos < end && nIdle >= refillMin) {                              // wave-uniform
             PS(0, min(nIdle, (int)(end - pos)));
@@ -371,15 +374,15 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 }
             }
             pos += (unsigned)nIdle;
-            nIdle = __popcll(__ballot(cur >= CUR_DONE));
+            nIdle = wavePop(__ballot(cur >= CUR_DONE));
         }
         if (nIdle == 64) { if (pos >= end) break; continue; }
         // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire.  Like the two traversal
         // phases below this one is worth a trip only for enough lanes: it runs when noneMin lanes wait for it, or when it is the
         // most wanted of the three
-        int nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
-        int nLeaf = __popcll(__ballot(cur < 0));
-        const int nNone = __popcll(__ballot(cur == CUR_NONE));
+        int nInner = wavePop(__ballot((unsigned)cur < (unsigned)CUR_NONE));   // cur in [0, CUR_NONE)
+        int nLeaf = wavePop(__ballot(cur < 0));
+        const int nNone = wavePop(__ballot(cur == CUR_NONE));
         if (nNone >= noneMin || (nNone > 0 && nNone >= nInner && nNone >= nLeaf)) {
             PS(1, nNone);
             if (cur == CUR_NONE) {
@@ -412,8 +415,8 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                     cur = CUR_DONE;
                 }
             }
-            nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));
-            nLeaf = __popcll(__ballot(cur < 0));
+            nInner = wavePop(__ballot((unsigned)cur < (unsigned)CUR_NONE));
+            nLeaf = wavePop(__ballot(cur < 0));
         }
         if (nInner >= nLeaf && nInner > 0) {
             // ---- inner-node steps (:521-532); repeated while most of the lanes that started the phase still sit on inner nodes
@@ -448,7 +451,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                         cur = CUR_NONE;
                     }
                 }
-                nInner = __popcll(__ballot((unsigned)cur < (unsigned)CUR_NONE));
+                nInner = wavePop(__ballot((unsigned)cur < (unsigned)CUR_NONE));
             } while (nInner > keepGoing);
         } else if (nLeaf > 0) {
             // ---- leaf steps: one triangle of the pending leaf per step (:483-520); repeated while most lanes still have
@@ -481,7 +484,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                         more = true;
                     }
                 }
-                nMore = __popcll(__ballot(more));
+                nMore = wavePop(__ballot(more));
             } while (nMore > keepGoing);
         }
     }
