@@ -154,6 +154,26 @@ PM_DEV void loadNode(const DevScene& sc, const float4* ldsN, int ref, float4& q0
         q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
     }
 }
+// The same fetch with both arms issued before either is waited for.  A wave whose lanes sit partly in the staged prefix and partly
+// beyond it runs both arms; the compiler gives them the same destination registers and therefore waits for the global loads of the
+// other lanes (vmcnt(0)) before it even issues the LDS reads — the two latencies add up.  Written as instructions, the two arms write
+// disjoint lanes of the same registers (memory returns are per lane; there is no hazard), and ONE wait covers both.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+PM_DEV void loadNode2(const DevScene& sc, const float4* ldsN, int ref, float4& q0, float4& q1, float4& q2, float4& q3) {
+    f32x4 a, b, c; f32x2 d;
+    asm volatile("" : "=v"(a), "=v"(b), "=v"(c), "=v"(d));            // one set of registers for both arms, defined by whichever arm the lane takes
+    if (ref < sc.ldsNodes) {
+        const unsigned addr = (unsigned)(size_t)(const __attribute__((address_space(3))) float4*)ldsN + 64u * (unsigned)ref;
+        asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b64 %3, %4 offset:48"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(addr) : "memory");
+    } else {
+        const float4* p = sc.nodes + 4 * (size_t)ref;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\tglobal_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx2 %3, %4, off offset:48"
+                     : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(p) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+    q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w); q2 = make_float4(c.x, c.y, c.z, c.w); q3 = make_float4(d.x, d.y, 0.0f, 0.0f);
+}
 PM_DEV void loadTri(const DevScene& sc, const float4* ldsT, int ti, float4& t0, float4& t1, float4& t2) {
     if (ti < sc.ldsTris) {
         const float4* p = ldsT + 3 * ti;

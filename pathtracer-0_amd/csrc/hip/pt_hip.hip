@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 PS(2, nInner);
                 if ((unsigned)cur < (unsigned)CUR_NONE) {
                     float4 q0, q1, q2, q3;
-                    loadNode(sc, ldsN, cur, q0, q1, q2, q3);
+                    loadNode2(sc, ldsN, cur, q0, q1, q2, q3);
                     if (COUNT) { c.nodes++; c.boxtests += 2; }
                     float Ld, Rd;
                     rayBox2(o, invD, q0, q1, q2, Ld, Rd);
