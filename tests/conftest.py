@@ -13,6 +13,16 @@ import ptimport  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # On a GPU box torch becomes the first HIP user of the test process, as it is in bench.py: a few GPU tests alias the library's
+    # device memory as torch tensors, and torch's lazy device initialisation once failed ("No HIP GPUs are available") when it
+    # came after dozens of render contexts of the same process.  (The streams of a GPU need distinct hardware queues, see bench.py.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
