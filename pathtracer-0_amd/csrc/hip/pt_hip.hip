@@ -327,8 +327,11 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 #ifdef PT_PHASE_STATS
     unsigned long long ps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // {trips, active lanes} x {refill, next-object/retire, inner, leaf}, outer trips, live lanes at outer trips
 #define PS(k, lanes) do { ps[2 * (k)]++; ps[2 * (k) + 1] += (unsigned long long)(lanes); } while (0)
+    unsigned long long pt_[5] = {0, 0, 0, 0, 0}, tPrev = __builtin_amdgcn_s_memtime();      // shader-clock cycles per phase: refill, next-object, inner, leaf, votes and the rest
+#define PTIME(k) do { const unsigned long long tNow_ = __builtin_amdgcn_s_memtime(); pt_[k] += tNow_ - tPrev; tPrev = tNow_; } while (0)
 #else
 #define PS(k, lanes) do { } while (0)
+#define PTIME(k) do { } while (0)
 #endif
     for (;;) {
         // ---- refill idle lanes from the wave's range
@@ -337,6 +340,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
         PS(4, 64 - nIdle);
         if (pos < end && nIdle >= refillMin) {                              // wave-uniform
             PS(0, min(nIdle, (int)(end - pos)));
+            PTIME(4);
             if (cur >= CUR_DONE) {
                 // the hit records of the rays that retired since the last refill leave together: one store instruction for all of them,
                 // neighbouring slots of one refill generation close in time (the lanes retire out of order)
@@ -375,6 +379,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
             }
             pos += (unsigned)nIdle;
             nIdle = wavePop(__ballot(cur >= CUR_DONE));
+            PTIME(0);
         }
         if (nIdle == 64) { if (pos >= end) break; continue; }
         // ---- lanes whose BVH is exhausted: next object (root box test :468), else ellipsoids + retire.  Like the two traversal
@@ -385,6 +390,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
         const int nNone = wavePop(__ballot(cur == CUR_NONE));
         if (nNone >= noneMin || (nNone > 0 && nNone >= nInner && nNone >= nLeaf)) {
             PS(1, nNone);
+            PTIME(4);
             if (cur == CUR_NONE) {
                 while (ob < obEnd) {
                     float rd; int rref;
@@ -417,7 +423,9 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
             }
             nInner = wavePop(__ballot((unsigned)cur < (unsigned)CUR_NONE));
             nLeaf = wavePop(__ballot(cur < 0));
+            PTIME(1);
         }
+        PTIME(4);
         if (nInner >= nLeaf && nInner > 0) {
             // ---- inner-node steps (:521-532); repeated while most of the lanes that started the phase still sit on inner nodes
             const int keepGoing = (nInner * keepEighths) >> 3;
@@ -453,6 +461,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 }
                 nInner = wavePop(__ballot((unsigned)cur < (unsigned)CUR_NONE));
             } while (nInner > keepGoing);
+            PTIME(2);
         } else if (nLeaf > 0) {
             // ---- leaf steps: one triangle of the pending leaf per step (:483-520); repeated while most lanes still have
             // triangles left in their leaf (the reference's builder can leave many triangles in one leaf)
@@ -486,6 +495,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
                 }
                 nMore = wavePop(__ballot(more));
             } while (nMore > keepGoing);
+            PTIME(3);
         }
     }
     if (cur == CUR_DONE) st.H[*slotL] = make_float4(closest, hu, hv, __int_as_float(prim));      // the rays that retired after the last refill
@@ -496,12 +506,13 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
         atomicAdd(&ctl->cnt[PT_CNT_BOXTESTS], (unsigned long long)c.boxtests);
     }
 #ifdef PT_PHASE_STATS
-    if (lane == 0) for (int k = 0; k < 10; k++) atomicAdd(&ctl->dbg[k], ps[k]);
+    if (lane == 0) { for (int k = 0; k < 10; k++) atomicAdd(&ctl->dbg[k], ps[k]); for (int k = 0; k < 5; k++) atomicAdd(&ctl->dbg[10 + k], pt_[k]); }
 #endif
 #if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     if (lane == 0 && waveId < 8192) { ctl->waveEnd[waveId] = __builtin_amdgcn_s_memrealtime(); ctl->waveStart[waveId] = tStart; }
 #endif
 #undef PS
+#undef PTIME
 }
 
 // trace() loop body + sample/job bookkeeping for every live path slot.

@@ -35,4 +35,8 @@ for k, nm in enumerate(("refill", "next-object/retire", "inner step", "leaf step
     trips, lanes = int(out[2 * k]), int(out[2 * k + 1])
     if trips:
         print(f"  {nm:20s} trips/seg x64 = {trips * 64 / seg:8.1f} lane-slots   active lanes/trip = {lanes / trips:5.1f} ({100 * lanes / trips / 64:4.1f} %)   active lane-trips/seg = {lanes / seg:6.2f}")
+tt = [int(x) for x in out[10:15]]
+if sum(tt):
+    print("  wave time by phase (shader clock, lane 0 of every wave): " + "  ".join(f"{nm} {100.0 * t / sum(tt):.1f} %" for nm, t in zip(("refill", "next-object/retire", "inner", "leaf", "votes+rest"), tt))
+          + f"   [{sum(tt) / seg:.0f} wave-cycles per segment]")
 r.close()
