@@ -13,8 +13,8 @@ extern "C" {
 /* Tuning knobs: 0 = path slots in flight (default 0 = automatic: one per job of a synchronous batch within [2^20, 2^22]; 5/8 of the
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
- * 5 = persistent block size (256/512/1024), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
- * 8 = cap on the blocks per CU of the persistent grid (default 4 = 8 waves per SIMD; never more than fit at once; 0 = no cap),
+ * 5 = persistent block size (64/128/256/512/1024, default 256), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
+ * 8 = cap on the blocks per CU of the persistent grid (default 0 = no cap: as many as are resident at once, 8 blocks of 256 threads = 8 waves per SIMD),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6),
  * 10 = inner-node records kept in breadth-first order (whole levels, the top of the trees); deeper ones are laid out depth-first,
  * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 32-bit; -1 = automatic */

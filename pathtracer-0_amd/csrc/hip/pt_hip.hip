@@ -284,7 +284,7 @@ template <typename T> struct StackElem { typedef T type; };
 template <> struct StackElem<Packed18> { typedef unsigned short type; };
 
 #ifndef PT_EP_WAVES
-#define PT_EP_WAVES 8        // waves per SIMD the register allocation must leave room for (4 blocks of 512 threads per CU)
+#define PT_EP_WAVES 8        // waves per SIMD the register allocation must leave room for (8 blocks of 256 threads per CU)
 #endif
 template <bool COUNT, typename StackT, int TPB, bool RARE>
 __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc, State st, const unsigned* qIn, int iter, int nSlots,
@@ -829,10 +829,10 @@ struct pt_ctx {
     bool countStats = false, timing = false;
     int ldsBudget = 20 * 1024;
     int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
-    int extendTpb = 512, extendCacheBytes = 16 * 1024, refillMin = 24, numCUs = 256;
+    int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
     int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
-    int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 4; int innerKeepEighths = 6;
+    int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 0; int innerKeepEighths = 6;
     int bfsNodes = 0x7fffffff;      // inner-node records kept in breadth-first order (whole levels); the rest follow depth-first (buildScene)
     uint64_t hostCnt[PT_CNT_N] = {0};
     struct KT { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; int64_t launches = 0; double ms = 0; std::vector<float> each; } kt[4];
@@ -1146,27 +1146,29 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
     size_t fixed = (size_t)std::min(sc.numObj, 8) * tpb * 4 + (size_t)c->stackDepth * tpb * (c->stackMode == 2 ? 4 : 2) + 64 + 32 * 8 + (size_t)tpb * 4;     // (+ the per-lane slot numbers)     // + the LDS copies of up to 8 object roots
     size_t avail = fixed < 160 * 1024 ? 160 * 1024 - fixed : 0;
     size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, avail);
-    {   // a smaller node tile (down to 6 KB) if that lets one more block — two more waves per SIMD — live on the CU: occupancy is worth
-        // more to this kernel than the last kilobytes of tile (C3: 12 KB ≈ 16 KB, 8 KB −1..5 %; 8 instead of 6 waves per SIMD +9 %)
+    {   // a smaller node tile (down to 2 KB; 6 KB under blocks of 512 threads and more) if that lets every wave slot of the CU be used:
+        // occupancy is worth more to this kernel than the last kilobytes of tile (8 instead of 6 waves per SIMD +9 %; tiles of 4, 8 and 16 KB
+        // measure the same, profiles/r02_y_*)
         const int want = std::min(c->extendMaxBlocksPerCU > 0 ? c->extendMaxBlocksPerCU : 2048 / tpb, 2048 / tpb);
         const size_t perBlock = (size_t)160 * 1024 / (size_t)std::max(want, 1);
-        if (fixed + cb + 16 > perBlock && perBlock > fixed + 16 + 6 * 1024) cb = std::min(cb, (perBlock - fixed - 16) & ~(size_t)63);
+        const size_t minTile = tpb >= 512 ? 6 * 1024 : 2 * 1024;
+        if (fixed + cb + 16 > perBlock && perBlock > fixed + 16 + minTile) cb = std::min(cb, (perBlock - fixed - 16) & ~(size_t)63);
     }
     sc.ldsNodes = (int)std::min<size_t>((size_t)sc.nNodes, cb / 64);
     sc.ldsTris = (sc.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)sc.ldsNodes * 64) / 48) : 0;
     size_t lds = (size_t)sc.ldsNodes * 64 + (size_t)sc.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
-    // Blocks per CU of the grid = what is resident at once (LDS per block; 2048 threads per CU), capped by pt_set_option 8 (default 4).
+    // Blocks per CU of the grid = what is resident at once (LDS per block; 2048 threads per CU), capped by pt_set_option 8 (default: no cap).
     // All waves of the grid start within 1 µs of each other (per-wave stamps of a -DPT_WAVE_STAMPS build, scripts/wave_ends.py).
-    // A grid LARGER than what is resident queues blocks behind the resident ones and is slower (5-16 blocks per CU on C3; C4 and C5,
-    // whose deeper traversal stacks leave room for 3 blocks only, lose 5 % and 13 % with 4).
+    // A grid LARGER than what is resident queues blocks behind the resident ones and is slower (with 512-thread blocks: 5-16 blocks per
+    // CU on C3; C4 and C5, whose deeper traversal stacks then left room for 3 blocks only, lost 5 % and 13 % with 4).
     int perCU = std::max(1, std::min((int)(160 * 1024 / std::max<size_t>(lds, 1)), 2048 / tpb));
     if (c->extendMaxBlocksPerCU > 0) perCU = std::min(perCU, c->extendMaxBlocksPerCU);
     int grid = c->numCUs * perCU;
     int maxUseful = (launched + tpb - 1) / tpb;                  // never more blocks than 1 lane per ray
     grid = std::max(1, std::min(grid, maxUseful));
 #define EP(COUNT, T, TPB) launchEP<COUNT, T, TPB>(c, pr, sc, lds, grid)
-#define EP_T(COUNT, T) do { if (tpb == 256) EP(COUNT, T, 256); else if (tpb == 512) EP(COUNT, T, 512); else EP(COUNT, T, 1024); } while (0)
+#define EP_T(COUNT, T) do { if (tpb == 64) EP(COUNT, T, 64); else if (tpb == 128) EP(COUNT, T, 128); else if (tpb == 256) EP(COUNT, T, 256); else if (tpb == 512) EP(COUNT, T, 512); else EP(COUNT, T, 1024); } while (0)
     if (c->countStats) { if (c->stackMode == 0) EP_T(true, short); else if (c->stackMode == 1) EP_T(true, Packed18); else EP_T(true, int); }
     else { if (c->stackMode == 0) EP_T(false, short); else if (c->stackMode == 1) EP_T(false, Packed18); else EP_T(false, int); }
 #undef EP
@@ -1807,10 +1809,10 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
         case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; return PT_OK;
         case 4: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "extend mode must be 0 or 1"); c->extendMode = (int)value; return PT_OK;
-        case 5: if (value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
+        case 5: if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 64, 128, 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
-        case 8: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "blocks per CU must be in [0,8]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
+        case 8: if (value < 0 || value > 32) return fail(PT_ERR_ARG, "blocks per CU must be in [0,32]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
         case 11: if (value < -1 || value > 2) return fail(PT_ERR_ARG, "stack mode must be -1 (automatic), 0, 1 or 2"); c->stackModeForce = (int)value; c->sceneDirty = true; return PT_OK;
         case 10: if (value < 0 || value > 0x7fffffff) return fail(PT_ERR_ARG, "breadth-first node count out of range"); c->bfsNodes = (int)value; c->sceneDirty = true; return PT_OK;

@@ -168,7 +168,7 @@ def test_render_parity_small(pt, oracle, renderer_mod, name, W, H, frames, mode)
     assert_same(got, ref, cnt, ocnt)
 
 
-@pytest.mark.parametrize("tpb,cache,refill", [(256, 0, 1), (512, 8192, 16), (1024, 65536, 48), (512, 150000, 64)])
+@pytest.mark.parametrize("tpb,cache,refill", [(256, 0, 1), (512, 8192, 16), (1024, 65536, 48), (512, 150000, 64), (64, 1024, 8), (128, 4096, 24)])
 def test_render_parity_persistent_variants(pt, oracle, renderer_mod, tpb, cache, refill):
     """persistent intersect kernel: block size, LDS tile size (partial / whole BVH) and refill threshold do not change results"""
     wl = pt.scenes.build("C3", 128, 72)
