@@ -97,6 +97,7 @@ struct MultiCtx {
     float4* dFull = nullptr;            // on devices[0]: W * H, un-tiled (whole-image groups)
     int* dAllMaps = nullptr;            // on devices[0]: packed slot -> global pixel, -1 = padding
     std::vector<int32_t> maps;          // the same on the host (pt_read_frame of a partial group)
+    bool gatherReady = false;           // the buffers above exist (allocated by the first gather)
     uint64_t gathers = 0;
 };
 
@@ -147,7 +148,9 @@ int multiGather(pt_ctx* g, int age, float4** out) {
         if (!img[i]) return fail(PT_ERR_ARG, "no image of that age yet (too few pt_next_image calls)");
     }
     HIP_TRY(hipSetDevice(M.devices[0]));
-    if (!M.dGathered) {
+    if (!M.gatherReady) {                  // first gather: its buffers.  A failure half-way leaves gatherReady false: the next call starts over
+        for (float4** p : {&M.dGathered, &M.dFull}) if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; }
+        if (M.dAllMaps) { HIP_TRY(hipFree(M.dAllMaps)); M.dAllMaps = nullptr; }
         HIP_TRY(hipMalloc((void**)&M.dGathered, total * 16));
         M.maps.resize(total);
         for (int r = 0; r < M.n; r++) if ((rc = pt_shard_map(g->W, g->H, M.shardBase + r, M.shardTotal, M.maps.data() + (size_t)r * nSlots, nSlots))) return rc;
@@ -156,9 +159,10 @@ int multiGather(pt_ctx* g, int age, float4** out) {
             HIP_TRY(hipMalloc((void**)&M.dAllMaps, total * 4));
             HIP_TRY(hipMemcpy(M.dAllMaps, M.maps.data(), total * 4, hipMemcpyHostToDevice));
         }
-        M.ev.assign(M.n, nullptr);
-        for (int i = 0; i < M.n; i++) { HIP_TRY(hipSetDevice(M.devices[i])); HIP_TRY(hipEventCreateWithFlags(&M.ev[i], hipEventDisableTiming)); }
+        if (M.ev.empty()) M.ev.assign(M.n, nullptr);
+        for (int i = 0; i < M.n; i++) if (!M.ev[i]) { HIP_TRY(hipSetDevice(M.devices[i])); HIP_TRY(hipEventCreateWithFlags(&M.ev[i], hipEventDisableTiming)); }
         HIP_TRY(hipSetDevice(M.devices[0]));
+        M.gatherReady = true;
     }
     // 1. per device: its streams' accumulators side by side, on the device's first stream (one stream: nothing to copy).  Without RCCL
     //    (one device) the block IS the gathered buffer.
