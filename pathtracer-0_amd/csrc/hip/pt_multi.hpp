@@ -10,8 +10,8 @@
 //    un-tiling kernel there.  No exchange during rendering; results are bit-identical for every stream count (K10).
 //  * several streams on ONE GPU: a device listed k times carries k shards, each with its own path pool and HIP stream.  The
 //    streams run unsynchronised, so the intersect kernel of one (instruction-issue and latency bound) overlaps the shading kernel of
-//    another (HBM bound) and every launch's tail is filled by the other stream's blocks: two streams per GPU render C3 9 %, C4
-//    24 % faster than one (profiles/r02_g_streams_per_gpu.txt).  Shards that share a device are gathered with device copies.
+//    another (HBM bound) and every launch's tail is filled by the other stream's blocks: two streams per GPU render C3 12 %, C4
+//    25 % faster than one (profiles/r02_g_streams_per_gpu.txt, r02_y_block_size.txt).  Shards that share a device are gathered with device copies.
 //  The two combine ({0,0,1,1,...}: equal multiplicity, a device's entries adjacent): per device its shards are copied into one
 //  staging block, the blocks travel in the one ncclGather.  pt_create_multi_part makes a group that holds only shards
 //  first..first+n-1 of a larger total (one process per GPU, each with its own streams): its gather stops at the packed block.
