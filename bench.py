@@ -228,6 +228,9 @@ def main():
         unshard = shard.Unsharder(W, H, world * K if world > 1 else 1, renderer.shard_map, dev, renderer=r, ranks=world, sync_before_unshard=True)
 
         def collect(age):                       # the library completes the image and packs this rank's block, RCCL gathers the blocks
+            # the block of the previous image must have left in its collective before the library packs the next one into the same buffer
+            # (dist.gather returns with torch's stream waiting for the RCCL kernel, not the host; ranks ahead of the root could overtake it)
+            torch.cuda.current_stream(dev).synchronize()
             packed = torch.as_tensor(shard._DevArray(r.gather_image(age), (n_block, 4)), device=dev)
             r.stream_wait()                     # the block was written on the library's stream; torch's collective runs on another
             if gloo:                            # rehearsal: the same gather on CPU tensors, the gathered blocks go back to the GPU for pt_unshard

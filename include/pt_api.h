@@ -112,7 +112,9 @@ int pt_image_device(pt_ctx* ctx, int age, void** dev_ptr, size_t* n_pixels);
 /* The whole FRAME image `age` pt_next_image calls ago as width*height RGBA32F in device memory (row 0 = bottom): completes that
  * image like pt_finish_image and, on a pt_create_multi context, performs its ONE collective (device copies + RCCL gather of the shard
  * accumulators on devices[0] + un-tiling kernel; stream-ordered there, not synchronised; the buffer is reused by the next gather).
- * On a one-stream context it is that context's own image; on a pt_create_multi_part context the group's packed block. */
+ * On a one-stream context it is that context's own image; on a pt_create_multi_part context the group's packed block.
+ * The buffer belongs to the context and is written again by the next pt_gather_image / pt_read_frame: a caller that hands it to an
+ * asynchronous consumer (a collective on another stream) waits for that consumer before the next call. */
 int pt_gather_image(pt_ctx* ctx, int age, void** full_dev);
 
 /* glFinish() (dispatch.java:598) */
