@@ -757,6 +757,40 @@ def _random_workload(pt, seed, W=72, H=44, ellipsoid_maps=False):
     return wl
 
 
+def _nested_shells_workload(pt, W=64, H=48, shells=11):
+    """concentric transmissive shells, each with its own Ni: a ray towards the centre pushes one refraction index per shell
+    (frag.glsl:833-836) — the index stack fills past its register-held slots 0-3, up to the ten the shader has (:136-158)"""
+    S = pt.scenes
+    sc = S._new_scene()
+    S._cornell_materials(sc)
+    for k in range(shells):
+        sc.addMaterial(f"shell{k}")
+        sc.setLastMtl("Tr", 1.0); sc.setLastMtl("Ni", 1.05 + 0.07 * k); sc.setLastMtl("Pr", 1)
+        sc.setLastMtl("Tf", (0.02 * (k % 3), 0.01, 0.03)); sc.setLastMtl("Density", 0.5)
+    o = S.Obj()
+    S._cornell_room(o, boxes=False)
+    for k in range(shells):
+        o.group(f"shell{k}"); o.usemtl(f"shell{k}")
+        o.mesh(*S.icosphere(1, (0.0, 0.55, 0.0), 0.52 - 0.04 * k))
+    sc.addObjectText(o.text(), 0, parentDirectory="")
+    return S._finish("shells", sc, W, H, S.CORNELL_CAM, S.CORNELL_ROT, (40, 50, 70), 4, 40)
+
+
+@pytest.mark.parametrize("shells", [5, 8, 11])
+def test_nested_transmissive_shells(pt, oracle, renderer_mod, shells):
+    """index-stack slots 4-9 (the state groups S1 / S2, shifted in memory by the shading kernel) and the silent drop at ten entries"""
+    wl = _nested_shells_workload(pt, shells=shells)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
+    assert_same(got, ref, cnt, ocnt)
+    r = renderer_mod.Renderer(wl.W, wl.H, devices=[0, 0])          # overlapped batches on the two-stream group
+    seeds = seeds_for(pt, 1, 4)
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch_async(1, seeds[:1]); r.render_batch_async(2, seeds[1:])
+    got = r.read_frame(); r.close()
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), wl.W, wl.H, 1, 4, seeds, nthreads=8)
+    assert_same(got, ref)
+
+
 @pytest.mark.parametrize("seed", list(range(1, 19)))
 def test_random_scenes(pt, oracle, renderer_mod, seed):
     wl = _random_workload(pt, seed, ellipsoid_maps=seed > 12)
