@@ -88,7 +88,10 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     prof, prof_name = None, f"profiles/pmc_{args.config}.json"
     if os.path.exists(os.path.join(ROOT, prof_name)):
         prof = json.load(open(os.path.join(ROOT, prof_name)))
-    out = {"kernel": "k_extend_persist", "avg_launch_ms": round(avg_ext, 4), "launches": n_ext, "segments_per_launch": round(seg_per_launch),
+    from pathtracer_0_amd import build as _build
+    src_hash = _build.kernel_source_hash()
+    stale = prof is not None and prof.get("kernel_source_hash") != src_hash      # the per-segment counter figures were measured on other kernels
+    out = {"kernel": "k_extend_persist", "counters_stale": bool(stale), "kernel_source_hash": src_hash, "avg_launch_ms": round(avg_ext, 4), "launches": n_ext, "segments_per_launch": round(seg_per_launch),
            "median_launch_ms": round(r.kernel_time_median("extend"), 4), "extend_share_of_step": round(ms_ext / max(world, 1) / (dt * 1e3), 3),
            "segments_per_sample": round(S, 3), "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3)}}
     ke = (prof or {}).get("kernels", {}).get("k_extend_persist")
@@ -134,7 +137,7 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
             chip["hbm"] = {"achieved": round(b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / HBM_PEAK_GBS, 4)}
         out["chip"] = chip
     out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "extend_GBps_if_streamed": round(b_ext * seg_rate / 1e9, 1),
-                          "bytes_per_sample_whole_path": round(b_samp, 1), "whole_path_GBps": round(b_samp * value * 1e6 / 1e9 / world, 1),
+                          "bytes_per_sample_whole_path": round(b_samp, 1), "whole_path_GBps_per_gpu": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1), 1),
                           "note": "SURVEY.md 8(d): 44 B per node visit, 36 B per triangle test, 124 B per hit update, 304 B of queue state per segment in the reference's "
                                   "layout; a bookkeeping figure, not a roofline fraction"}
     return out
@@ -341,7 +344,7 @@ def main():
     out = {
         "metric": METRIC, "value": round(value, 3), "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "hip_runtime": renderer.hip_runtime_info(),
         "config": {"workload": f"{args.config}: {W}x{H}, {cfg['bounces']}-bounce, {spp_step} spp/step ({fps} frames x SAMPLE_RES {sample_res}), "
                                f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs, tile-sharded over {shards} shard(s) on {n_gpus} GPU(s), 1 framebuffer gather per step",
                    "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"], "multi_gpu": how},

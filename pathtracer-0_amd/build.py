@@ -39,6 +39,18 @@ def build_hip(force=False, extra=()):
     return out
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the device sources, in name order: committed counter summaries (profiles/pmc_*.json) carry it, and
+    bench.py flags them stale when the kernels have changed underneath"""
+    import hashlib
+    d = os.path.join(HERE, "csrc", "hip")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".s", ".inc")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_all(force=False):
     return build_host(force), build_hip(force)
 

@@ -777,6 +777,10 @@ __global__ void k_debug_math(int fn, const float* x, const float* y, float* out,
         case 3: r = exp_(x[i]); break;
         case 4: r = atan2_(x[i], y[i]); break;
         case 5: r = asin_(x[i]); break;
+        // the RNG of frag.glsl:686-694 on the device (K1 vectors): x carries the uint32 state as bits
+        case 6: { uint32_t st = __float_as_uint(x[i]); NextRandom(st); r = __uint_as_float(st); break; }                     // state after one call
+        case 7: { uint32_t st = __float_as_uint(x[i]); r = __uint_as_float(NextRandom(st)); break; }                         // result of that call
+        case 8: { uint32_t st = __float_as_uint(x[i]); r = random_(st); break; }                                             // random()
         default: r = __builtin_nanf("");
     }
     out[i] = r;
@@ -839,6 +843,11 @@ struct pt_ctx {
 };
 
 namespace {
+
+struct Scratch {            // device allocations of one call: released whichever way the call returns
+    std::vector<void**> ptrs;
+    ~Scratch() { for (void** p : ptrs) if (*p) { hipFree(*p); *p = nullptr; } }
+};
 
 int uploadVec(void** dptr, const void* src, size_t bytes, hipStream_t s) {
     if (*dptr) { HIP_TRY(hipFree(*dptr)); *dptr = nullptr; }
@@ -1446,6 +1455,9 @@ int pt_set_error_(int code, const std::string& msg) { return fail(code, msg); } 
 
 // a group context hands the call to the host thread of every device context and joins them (pt_multi.hpp)
 #define MULTI_ALL(c, call) do { if ((c) && (c)->multi) return multiRun(*(c)->multi, [=](pt_ctx* k) { return call; }); } while (0)
+// ... for the entry points that render: not while an upload reached only some of the streams
+#define MULTI_RENDER(c, call) do { if ((c) && (c)->multi) { if (!(c)->multi->staleBindings.empty()) return fail(PT_ERR_SCENE, "an earlier pt_set_buffer / pt_set_texture failed after it had reached some of the context's streams: repeat that upload before rendering"); \
+                                                          return multiRun(*(c)->multi, [=](pt_ctx* k) { return call; }); } } while (0)
 
 extern "C" {
 
@@ -1502,9 +1514,6 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
 int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int width, int height, int first_shard, int total_shards) {
     if (!out || !devices || n_devices < 1 || n_devices > 64 || width < 1 || height < 1 || first_shard < 0 || total_shards < n_devices || first_shard + n_devices > total_shards)
         return fail(PT_ERR_ARG, "pt_create_multi: bad argument");
-    // streams that share a GPU overlap only on different hardware queues; the runtime deals them round-robin when this is set (it is read
-    // once, when the process initialises HIP: a host that has used HIP before this call sets it itself)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev < 1) return fail(PT_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)");
     for (int i = 0; i < n_devices; i++) if (devices[i] < 0 || devices[i] >= nDev) return fail(PT_ERR_NO_DEVICE, "pt_create_multi: HIP device index out of range");
@@ -1516,6 +1525,19 @@ int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int wi
         runs.push_back(MultiCtx::Run{devices[i], i, 1, nullptr});
     }
     for (const auto& r : runs) if (r.count != runs[0].count) return fail(PT_ERR_ARG, "pt_create_multi: every device must be listed the same number of times");
+    // Test mode (tests/test_gpu_multi.py): PT_MULTI_VIRTUAL_DEVICES=k splits the streams of ONE device into k "virtual devices", so that a
+    // one-GPU box runs the several-device code of the gather — a staging block per device, root and non-root arguments, block offsets,
+    // the un-tiling of a gathered buffer — with the RCCL calls replaced by device copies to the offsets ncclGather writes (pt_multi.hpp).
+    int virtualDevices = 0;
+    if (const char* vd = getenv("PT_MULTI_VIRTUAL_DEVICES")) {
+        virtualDevices = atoi(vd);
+        if (virtualDevices > 1) {
+            if (runs.size() != 1 || n_devices % virtualDevices) return fail(PT_ERR_ARG, "PT_MULTI_VIRTUAL_DEVICES=k needs ONE device listed a multiple of k times");
+            const int per = n_devices / virtualDevices, dev = runs[0].device;
+            runs.clear();
+            for (int v = 0; v < virtualDevices; v++) runs.push_back(MultiCtx::Run{dev, v * per, per, nullptr});
+        } else virtualDevices = 0;
+    }
     pt_ctx* g = new pt_ctx();
     g->W = width; g->H = height; g->device = devices[0];
     MultiCtx* M = new MultiCtx();
@@ -1524,6 +1546,7 @@ int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int wi
     M->shardBase = first_shard; M->shardTotal = total_shards;
     const char* force = getenv("PT_MULTI_FORCE_RCCL");          // tests: the RCCL call path of a one-device group on a one-GPU box
     M->useRccl = runs.size() > 1 || (force && force[0] == '1');
+    M->virtualDevices = virtualDevices > 1;
     M->kids.assign(n_devices, nullptr);
     for (int i = 0; i < n_devices; i++) {
         M->workers.emplace_back(new Worker());
@@ -1538,6 +1561,14 @@ int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int wi
     for (int i = 0; i < n_devices; i++) { int r = M->workers[i]->wait(); if (r && !rc) { rc = r; err = "device " + std::to_string(devices[i]) + ": " + M->workers[i]->err; } }
     if (rc) { M->kids.erase(std::remove(M->kids.begin(), M->kids.end(), nullptr), M->kids.end()); multiFree(g); delete g; return fail(rc, err); }
     *out = g;
+    // Streams that share a GPU overlap only on different hardware queues.  The HIP runtime deals streams to queues round-robin when
+    // GPU_MAX_HW_QUEUES is set — a variable it reads ONCE, when the process initialises HIP, so it is the host's to set;
+    // the library does not touch the process environment.  Without it the context works, at the speed of one stream: said here, once,
+    // as a warning that pt_last_error() returns after this successful call.
+    g_err.clear();
+    if (n_devices > (int)runs.size() && !getenv("GPU_MAX_HW_QUEUES"))
+        g_err = "warning: several streams share a GPU but GPU_MAX_HW_QUEUES is not set in the environment: the HIP runtime may put them on one hardware queue "
+                "and their kernels will not overlap (set GPU_MAX_HW_QUEUES=8 before the process first uses HIP)";
     return PT_OK;
 }
 
@@ -1565,7 +1596,16 @@ int pt_destroy(pt_ctx* c) {
 
 int pt_set_buffer(pt_ctx* c, int binding, const void* data, size_t bytes) {
     if (!c || (!data && bytes)) return fail(PT_ERR_ARG, "pt_set_buffer: null argument");
-    if (c->multi) { for (pt_ctx* k : c->multi->kids) { int rc = pt_set_buffer(k, binding, data, bytes); if (rc) return rc; } return PT_OK; }      // the scene is replicated
+    if (c->multi) {                                               // the scene is replicated
+        for (pt_ctx* k : c->multi->kids) {
+            int rc = pt_set_buffer(k, binding, data, bytes);
+            // the checks are the same for every stream, so the first one refuses a bad upload before anything changed; a failure later on
+            // (out of memory) leaves the replicas different: no render until this binding has reached all of them
+            if (rc) { if (k != c->multi->kids[0]) c->multi->staleBindings.insert(binding); return rc; }
+        }
+        c->multi->staleBindings.erase(binding);
+        return PT_OK;
+    }
     if (bytes % 4) return fail(PT_ERR_ARG, "pt_set_buffer: size must be a multiple of 4 bytes");
     const float* f = static_cast<const float*>(data); const int32_t* i = static_cast<const int32_t*>(data); size_t n = bytes / 4;
     switch (binding) {
@@ -1589,7 +1629,14 @@ int pt_set_buffer(pt_ctx* c, int binding, const void* data, size_t bytes) {
 
 int pt_set_texture(pt_ctx* c, int index, int w, int h, const uint8_t* rgba8) {
     if (!c || !rgba8 || w < 1 || h < 1) return fail(PT_ERR_ARG, "pt_set_texture: bad argument");
-    if (c->multi) { for (pt_ctx* k : c->multi->kids) { int rc = pt_set_texture(k, index, w, h, rgba8); if (rc) return rc; } return PT_OK; }
+    if (c->multi) {
+        for (pt_ctx* k : c->multi->kids) {
+            int rc = pt_set_texture(k, index, w, h, rgba8);
+            if (rc) { if (k != c->multi->kids[0]) c->multi->staleBindings.insert(1000 + index); return rc; }
+        }
+        c->multi->staleBindings.erase(1000 + index);
+        return PT_OK;
+    }
     if (index < 0 || index > 4095) return fail(PT_ERR_ARG, "texture index out of range [0,4095]");
     if (index == 0) { c->sky.assign(rgba8, rgba8 + (size_t)w * h * 4); c->skyW = w; c->skyH = h; }
     if ((size_t)index >= c->textures.size()) c->textures.resize((size_t)index + 1);
@@ -1610,18 +1657,18 @@ int pt_reset_frame(pt_ctx* c) {
 
 int pt_render(pt_ctx* c, int frame_count, int seed) {
     if (!c) return fail(PT_ERR_ARG, "null context");
-    MULTI_ALL(c, pt_render(k, frame_count, seed));
+    MULTI_RENDER(c, pt_render(k, frame_count, seed));
     int32_t s = seed;
     return submitBatch(c, frame_count, 1, &s, false);
 }
 int pt_render_batch(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
     if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch: null argument");
-    MULTI_ALL(c, pt_render_batch(k, first_frame, n_frames, seeds));
+    MULTI_RENDER(c, pt_render_batch(k, first_frame, n_frames, seeds));
     return submitBatch(c, first_frame, n_frames, seeds, false);
 }
 int pt_render_batch_async(pt_ctx* c, int first_frame, int n_frames, const int32_t* seeds) {
     if (!c || !seeds) return fail(PT_ERR_ARG, "pt_render_batch_async: null argument");
-    MULTI_ALL(c, pt_render_batch_async(k, first_frame, n_frames, seeds));
+    MULTI_RENDER(c, pt_render_batch_async(k, first_frame, n_frames, seeds));
     return submitBatch(c, first_frame, n_frames, seeds, true);
 }
 
@@ -1912,14 +1959,14 @@ int pt_debug_math(pt_ctx* c, int fn, const float* x, const float* y, float* out,
     if (!c || !x || !out) return fail(PT_ERR_ARG, "pt_debug_math: null argument");
     if (c->multi) c = c->multi->kids[0];
     HIP_TRY(hipSetDevice(c->device));
-    float *dx, *dy, *dout;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    Scratch scratch{{(void**)&dx, (void**)&dy, (void**)&dout}};       // freed on every return path
     HIP_TRY(hipMalloc((void**)&dx, n * 4)); HIP_TRY(hipMalloc((void**)&dy, n * 4)); HIP_TRY(hipMalloc((void**)&dout, n * 4));
     HIP_TRY(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
     if (y) HIP_TRY(hipMemcpy(dy, y, n * 4, hipMemcpyHostToDevice)); else HIP_TRY(hipMemset(dy, 0, n * 4));
     hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, fn, dx, dy, dout, n);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(dy); hipFree(dout);
     return PT_OK;
 }
 
@@ -1938,6 +1985,7 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
         g1[4 * i] = d[3 * i + 1]; g1[4 * i + 1] = d[3 * i + 2]; uint32_t fl = FL_ALIVE; std::memcpy(&g1[4 * i + 3], &fl, 4);
     }
     State st{};
+    Scratch scratch{{(void**)&st.G0, (void**)&st.G1, (void**)&st.H}};  // freed on every return path
     HIP_TRY(hipMalloc((void**)&st.G0, np * 16)); HIP_TRY(hipMalloc((void**)&st.G1, np * 16)); HIP_TRY(hipMalloc((void**)&st.H, np * 16));
     HIP_TRY(hipMemcpy(st.G0, g0.data(), np * 16, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(st.G1, g1.data(), np * 16, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(st.H, 0, np * 16));
@@ -1954,7 +2002,6 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     std::vector<float> h(np * 4);
     HIP_TRY(hipMemcpy(h.data(), st.H, np * 16, hipMemcpyDeviceToHost));
     std::memcpy(out, h.data(), n * 16);
-    hipFree(st.G0); hipFree(st.G1); hipFree(st.H);
     return PT_OK;
 }
 

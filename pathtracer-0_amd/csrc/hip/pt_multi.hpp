@@ -24,6 +24,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <thread>
 
 #include <rccl/rccl.h>
@@ -90,6 +91,7 @@ struct MultiCtx {
     struct Run { int device, first, count; float4* staging; };      // the streams of one device
     std::vector<Run> runs;
     bool useRccl = false;               // more than one distinct device (or PT_MULTI_FORCE_RCCL=1: the RCCL call path on a one-GPU box)
+    bool virtualDevices = false;        // test mode PT_MULTI_VIRTUAL_DEVICES: the runs share one GPU, the transport between them is device copies
     std::vector<std::unique_ptr<Worker>> workers;
     std::vector<ncclComm_t> comms;      // one per run
     std::vector<hipEvent_t> ev;         // per stream: "this shard's image is complete"; ev[run.first] doubles as "the copies have read it"
@@ -98,6 +100,7 @@ struct MultiCtx {
     int* dAllMaps = nullptr;            // on devices[0]: packed slot -> global pixel, -1 = padding
     std::vector<int32_t> maps;          // the same on the host (pt_read_frame of a partial group)
     bool gatherReady = false;           // the buffers above exist (allocated by the first gather)
+    std::set<int> staleBindings;        // bindings (textures: 1000 + index) whose last upload reached only some of the streams: no render until repeated
     uint64_t gathers = 0;
 };
 
@@ -185,23 +188,37 @@ int multiGather(pt_ctx* g, int age, float4** out) {
     }
     // 2. across devices: ONE ncclGather, a block per device, root = devices[0]
     if (M.useRccl) {
-        if ((rc = g_rccl.load())) return rc;
-        if (M.comms.empty()) {
+        if (!M.virtualDevices && (rc = g_rccl.load())) return rc;
+        if (!M.virtualDevices && M.comms.empty()) {
             std::vector<int> devs;
             for (auto& run : M.runs) devs.push_back(run.device);
             M.comms.assign(M.runs.size(), nullptr);
-            RCCL_TRY(g_rccl.CommInitAll(M.comms.data(), (int)devs.size(), devs.data()));
+            const ncclResult_t e = g_rccl.CommInitAll(M.comms.data(), (int)devs.size(), devs.data());
+            if (e != ncclSuccess) { M.comms.clear(); return fail(PT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(e)); }      // the next call starts over
         }
-        RCCL_TRY(g_rccl.GroupStart());
+        if (!M.virtualDevices) RCCL_TRY(g_rccl.GroupStart());
         for (size_t r = 0; r < M.runs.size(); r++) {
             const auto& run = M.runs[r];
-            HIP_TRY(hipSetDevice(run.device));
+            // every exit from inside the group closes it: an open group would swallow the next call's collectives
+            { const hipError_t he = hipSetDevice(run.device); if (he != hipSuccess) { if (!M.virtualDevices) g_rccl.GroupEnd(); return fail(PT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he)); } }
             const float4* send = run.count == 1 ? img[run.first] : run.staging;
             // recvbuff matters on the root only; the other ranks pass a valid local pointer that is never written
-            ncclResult_t e = g_rccl.Gather(send, r == 0 ? (void*)M.dGathered : (void*)send, (size_t)run.count * nSlots * 4, ncclFloat, 0, M.comms[r], M.kids[run.first]->stream);
+            void* const recv = r == 0 ? (void*)M.dGathered : (void*)send;
+            const size_t floats = (size_t)run.count * nSlots * 4;
+            hipStream_t const strm = M.kids[run.first]->stream;
+            if (M.virtualDevices) {
+                // what ncclGather does with these arguments, by device copies: rank r's block lands at r * count in the root's receive buffer,
+                // and the root's stream continues once every block has arrived
+                hipError_t he = hipMemcpyAsync((float*)M.dGathered + r * floats, send, floats * 4, hipMemcpyDeviceToDevice, strm);
+                if (he == hipSuccess && r > 0) { he = hipEventRecord(M.ev[run.first], strm); if (he == hipSuccess) he = hipStreamWaitEvent(root->stream, M.ev[run.first], 0); }
+                if (he != hipSuccess) return fail(PT_ERR_HIP, std::string("virtual-device gather: ") + hipGetErrorString(he));
+                (void)recv;
+                continue;
+            }
+            ncclResult_t e = g_rccl.Gather(send, recv, floats, ncclFloat, 0, M.comms[r], strm);
             if (e != ncclSuccess) { g_rccl.GroupEnd(); return fail(PT_ERR_HIP, std::string("ncclGather: ") + g_rccl.GetErrorString(e)); }
         }
-        RCCL_TRY(g_rccl.GroupEnd());
+        if (!M.virtualDevices) RCCL_TRY(g_rccl.GroupEnd());
     }
     HIP_TRY(hipSetDevice(M.devices[0]));
     M.gathers++;

@@ -17,6 +17,17 @@ static void throw_rt(JNIEnv* env, const char* where) {
     snprintf(msg, sizeof msg, "%s: %s", where, pt_last_error());
     (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/RuntimeException"), msg);
 }
+/* address of a direct NIO buffer, or NULL with an IllegalArgumentException pending: heap buffers and null references never reach
+ * the library.  (GetDirectBufferCapacity counts ELEMENTS of the buffer's type, so sizes are checked on the Java side, PtNative.java.) */
+static void* direct(JNIEnv* env, jobject buf, const char* where) {
+    void* p = buf ? (*env)->GetDirectBufferAddress(env, buf) : NULL;
+    if (!p) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "%s needs a direct NIO buffer (BufferUtils.create*Buffer / ByteBuffer.allocateDirect)", where);
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), msg);
+    }
+    return p;
+}
 #define CHECK(call, where) do { if ((call) != PT_OK) { throw_rt(env, where); return; } } while (0)
 #define CTX(h) ((pt_ctx*)(intptr_t)(h))
 
@@ -46,12 +57,14 @@ JNIEXPORT jlong JNICALL Java_Main_PtNative_createMultiPart(JNIEnv* env, jclass c
 JNIEXPORT void JNICALL Java_Main_PtNative_streamWait(JNIEnv* env, jclass c, jlong h) { CHECK(pt_stream_wait(CTX(h)), "pt_stream_wait"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_destroy(JNIEnv* env, jclass c, jlong h) { pt_destroy(CTX(h)); }
 JNIEXPORT void JNICALL Java_Main_PtNative_setBuffer(JNIEnv* env, jclass c, jlong h, jint binding, jobject buf, jlong bytes) {
-    void* p = (*env)->GetDirectBufferAddress(env, buf);
-    if (!p) { (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "setBuffer needs a direct NIO buffer"); return; }
+    void* p = direct(env, buf, "setBuffer");
+    if (!p) return;
     CHECK(pt_set_buffer(CTX(h), binding, p, (size_t)bytes), "pt_set_buffer");
 }
 JNIEXPORT void JNICALL Java_Main_PtNative_setTexture(JNIEnv* env, jclass c, jlong h, jint index, jint w, jint ht, jobject buf) {
-    CHECK(pt_set_texture(CTX(h), index, w, ht, (const uint8_t*)(*env)->GetDirectBufferAddress(env, buf)), "pt_set_texture");
+    void* p = direct(env, buf, "setTexture");
+    if (!p) return;
+    CHECK(pt_set_texture(CTX(h), index, w, ht, (const uint8_t*)p), "pt_set_texture");
 }
 JNIEXPORT void JNICALL Java_Main_PtNative_resetFrame(JNIEnv* env, jclass c, jlong h) { CHECK(pt_reset_frame(CTX(h)), "pt_reset_frame"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_render(JNIEnv* env, jclass c, jlong h, jint frameCount, jint seed) { CHECK(pt_render(CTX(h), frameCount, seed), "pt_render"); }
@@ -97,9 +110,13 @@ JNIEXPORT void JNICALL Java_Main_PtNative_renderAsync(JNIEnv* env, jclass c, jlo
     CHECK(pt_render_batch_async(CTX(h), frameCount, 1, &s), "pt_render_batch_async");
 }
 JNIEXPORT void JNICALL Java_Main_PtNative_readDisplay(JNIEnv* env, jclass c, jlong h, jint frameCount, jboolean javaBytes, jobject out) {
-    CHECK(pt_read_display(CTX(h), frameCount, javaBytes ? 1 : 0, (uint8_t*)(*env)->GetDirectBufferAddress(env, out)), "pt_read_display");
+    void* p = direct(env, out, "readDisplay");
+    if (!p) return;
+    CHECK(pt_read_display(CTX(h), frameCount, javaBytes ? 1 : 0, (uint8_t*)p), "pt_read_display");
 }
 JNIEXPORT void JNICALL Java_Main_PtNative_synchronize(JNIEnv* env, jclass c, jlong h) { CHECK(pt_synchronize(CTX(h)), "pt_synchronize"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_readFrame(JNIEnv* env, jclass c, jlong h, jobject out) {
-    CHECK(pt_read_frame(CTX(h), (float*)(*env)->GetDirectBufferAddress(env, out)), "pt_read_frame");
+    void* p = direct(env, out, "readFrame");
+    if (!p) return;
+    CHECK(pt_read_frame(CTX(h), (float*)p), "pt_read_frame");
 }

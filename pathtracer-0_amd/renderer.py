@@ -21,13 +21,61 @@ OPTIONS = {"path_slots": 0, "count_stats": 1, "lds_budget": 2, "none_min": 3, "e
            "refill_min": 7, "extend_blocks_per_cu": 8, "inner_keep_eighths": 9, "bfs_nodes": 10, "stack_mode": 11}
 
 
+def hip_runtimes_mapped():
+    """real paths of every libamdhip64 mapped into this process (Linux)"""
+    out = set()
+    try:
+        for line in open("/proc/self/maps"):
+            p = line.rstrip("\n").split(" ")[-1]
+            if "libamdhip64" in os.path.basename(p):
+                out.add(os.path.realpath(p))
+    except OSError:
+        pass
+    return sorted(out)
+
+
+def hip_runtime_info():
+    """{"path", "version"} of the HIP runtime this process runs on (hipRuntimeGetVersion of the mapped libamdhip64)"""
+    rts = hip_runtimes_mapped()
+    if not rts:
+        return {"path": None, "version": None}
+    v = C.c_int(0)
+    try:
+        C.CDLL(rts[0]).hipRuntimeGetVersion(C.byref(v))
+    except (OSError, AttributeError):
+        pass
+    return {"path": rts[0], "version": v.value, "runtimes_mapped": len(rts)}
+
+
+def _load_one_hip_runtime(path):
+    """libpt_hip.so is linked against libamdhip64.so.7 (RUNPATH: the ROCm installation it was built with).  PyTorch ships its OWN
+    libamdhip64.so with the same SONAME.  A process must run on ONE of them:
+      * torch imported first  -> the dynamic loader resolves the library's libamdhip64.so.7 to torch's copy, already mapped: one runtime;
+      * library loaded first  -> ROCm's runtime is mapped and initialises the GPU; a later `import torch` maps a SECOND runtime, which finds
+        no device ("No HIP GPUs are available", profiles/r03_a_hip_runtime_probe.txt — the failure conftest.py used to paper over).
+    So: a Python host that will also use torch (bench.py, the tests, shard.py) gets torch imported here, before the library; a process that
+    ends up with two runtimes mapped is refused.  PT_NO_TORCH=1: never import torch (a torch-free host; it then runs on ROCm's runtime)."""
+    import sys
+    if "torch" not in sys.modules and os.environ.get("PT_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401  (maps torch's HIP runtime first)
+        except ImportError:
+            pass
+    L = C.CDLL(path)
+    rts = hip_runtimes_mapped()
+    if len(rts) > 1 and os.environ.get("PT_ALLOW_TWO_HIP_RUNTIMES") != "1":
+        raise RuntimeError("two HIP runtimes are mapped into this process: " + ", ".join(rts) + ".  libpt_hip.so and PyTorch must share one: "
+                           "import torch BEFORE the first pathtracer_0_amd.renderer call (or set PT_NO_TORCH=1 and do not import torch at all)")
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
         path = os.environ.get("PT_HIP_LIB") or os.path.join(_HERE, "libpt_hip.so")     # PT_HIP_LIB: A/B builds of the same ABI (tuning only)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: the HIP extension is required (no fallback). Build it with __graft_entry__.build()")
-        L = C.CDLL(path)
+        L = _load_one_hip_runtime(path)
         vp, ci, sz = C.c_void_p, C.c_int, C.c_size_t
         L.pt_last_error.restype = C.c_char_p
         L.pt_create.argtypes = [C.POINTER(vp), ci, ci, ci, ci, ci]
@@ -107,6 +155,10 @@ class Renderer:
             arr = (C.c_int * len(self.devices))(*self.devices)
             self.first_shard, self.total_shards = int(first_shard), int(total_shards if total_shards is not None else len(self.devices))
             _check(self._L.pt_create_multi_part(C.byref(self._h), arr, len(self.devices), W, H, self.first_shard, self.total_shards))
+            note = self._L.pt_last_error().decode()
+            if note.startswith("warning:"):
+                import warnings
+                warnings.warn(note[len("warning:"):].strip())
         else:
             _check(self._L.pt_create(C.byref(self._h), device, W, H, shard_rank, shard_count))
 
@@ -235,7 +287,8 @@ class Renderer:
 
     # --- parity probes --------------------------------------------------------------------------
     def debug_math(self, fn, x, y=None):
-        names = {"sin": 0, "cos": 1, "log": 2, "exp": 3, "atan2": 4, "asin": 5}
+        # rng_state / rng_result / rng_random: one NextRandom / random() call of frag.glsl:686-694, the uint32 state travels as float bits
+        names = {"sin": 0, "cos": 1, "log": 2, "exp": 3, "atan2": 4, "asin": 5, "rng_state": 6, "rng_result": 7, "rng_random": 8}
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)
         yp = None if y is None else np.ascontiguousarray(y, dtype=np.float32).ctypes.data

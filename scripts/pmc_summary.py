@@ -19,9 +19,18 @@ VALU issue roof: 256 CUs * 4 SIMDs * 2.4 GHz / 2 cycles per wave64 instruction =
 import collections
 import csv
 import glob
+import importlib.util
 import json
+import os
 import re
 import sys
+
+
+def kernel_source_hash():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pt_build", os.path.join(root, "pathtracer-0_amd", "build.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m.kernel_source_hash()
 
 VALU_PEAK = 256 * 4 * 2.4e9 / 2
 HBM_PEAK = 8.0e12
@@ -41,7 +50,8 @@ def main(d, cfg, fps):
             a[0] += 1
             a[1] += float(row["Counter_Value"])
     out = {"source": d, "config": cfg, "frames_per_step": fps, "command": f"rocprofv3 --pmc <set> -- python3 bench.py --config {cfg} --steps 1 --warmup 0 "
-           f"--frames-per-step {fps} --no-cpu-baseline --no-roofline", "valu_issue_peak_per_s": VALU_PEAK, "kernels": {}}
+           f"--frames-per-step {fps} --no-cpu-baseline --no-roofline", "valu_issue_peak_per_s": VALU_PEAK,
+           "kernel_source_hash": kernel_source_hash(), "kernels": {}}
     if plain:
         rf = plain.get("roofline", {})
         W, H = plain["config"]["width"], plain["config"]["height"]

@@ -13,15 +13,16 @@ import ptimport  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # On a GPU box torch becomes the first HIP user of the test process, as it is in bench.py: a few GPU tests alias the library's
-    # device memory as torch tensors, and torch's lazy device initialisation once failed ("No HIP GPUs are available") when it
-    # came after dozens of render contexts of the same process.  (The streams of a GPU need distinct hardware queues, see bench.py.)
+    # torch is imported BEFORE libpt_hip.so is loaded: PyTorch ships its own libamdhip64.so with the SONAME the library is linked against,
+    # and a process must run on one HIP runtime.  Library first = ROCm's runtime initialises the GPU, torch then maps a second runtime
+    # that finds no device ("No HIP GPUs are available": the round-2 failure of test_overlapped_batches_equal_synchronous, reproduced in
+    # profiles/r03_a_hip_runtime_probe.txt).  renderer.lib() enforces the order and refuses a process with two runtimes mapped; the import
+    # here only makes the order explicit for the tests that alias device memory as torch tensors.
+    # (The streams of a GPU need distinct hardware queues: a variable the HIP runtime reads once, so it is set before anything uses HIP.)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
+        import torch  # noqa: F401
+    except ImportError:
         pass
 
 

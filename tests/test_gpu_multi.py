@@ -58,6 +58,36 @@ def test_multi_context_equals_single(pt, renderer_mod, devices, W, H):
     r1.close()
 
 
+@pytest.mark.parametrize("devices,virtual,W,H", [([0, 0, 0, 0], 2, 100, 37), ([0, 0, 0], 3, 96, 54), ([0, 0, 0, 0, 0, 0, 0, 0], 4, 160, 90), ([0, 0, 0, 0, 0, 0], 2, 70, 41)])
+def test_several_device_gather_on_virtual_devices(pt, renderer_mod, devices, virtual, W, H, monkeypatch):
+    """The several-DEVICE code of the gather (pt_multi.hpp: one staging block per device — none for a device with one stream —, root and
+    non-root arguments of the collective, block offsets, un-tiling of the gathered buffer) on a one-GPU box: PT_MULTI_VIRTUAL_DEVICES=k
+    splits the streams of GPU 0 into k devices and replaces only the RCCL calls, by device copies to the offsets ncclGather writes.
+    {0,0|0,0} is the production shape of a 2-GPU node (two streams per GPU), {0|0|0} three GPUs with one stream each."""
+    monkeypatch.setenv("PT_MULTI_VIRTUAL_DEVICES", str(virtual))
+    wl = pt.scenes.build("C3", W, H)
+    seeds = _seeds(pt, 3)
+    rm = renderer_mod.Renderer(W, H, devices=devices)
+    monkeypatch.delenv("PT_MULTI_VIRTUAL_DEVICES")
+    rm.load_workload(wl); rm.reset_frame(); rm.render_batch(1, seeds)
+    got = rm.read_frame().copy()
+    disp = rm.read_display(3)
+    rm.next_image(); rm.render_batch_async(1, seeds[:2]); rm.render_batch_async(3, seeds[2:])
+    again = rm.read_frame().copy()                              # a second image through the same staging blocks
+    rm.close()
+    r1 = renderer_mod.Renderer(W, H)
+    r1.load_workload(wl); r1.reset_frame(); r1.render_batch(1, seeds)
+    ref = r1.read_frame(); ref_disp = r1.read_display(3); r1.close()
+    assert np.array_equal(got, ref, equal_nan=True) and np.array_equal(again, ref, equal_nan=True)
+    assert np.array_equal(disp, ref_disp)
+
+
+def test_virtual_devices_argument_checks(renderer_mod, monkeypatch):
+    monkeypatch.setenv("PT_MULTI_VIRTUAL_DEVICES", "2")
+    with pytest.raises(renderer_mod.PtError):
+        renderer_mod.Renderer(64, 64, devices=[0, 0, 0])         # 3 streams do not split into 2 devices
+
+
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
 def test_multi_context_through_rccl(pt, renderer_mod, devices, monkeypatch):
     """the gather of the several-GPU form (staging block per device + ONE ncclGather + un-tiling), forced onto the one device of this box"""

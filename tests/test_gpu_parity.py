@@ -72,6 +72,20 @@ def test_math_contract_atan2_and_unit_randoms(oracle, renderer_mod):
     assert np.array_equal(gl.view(np.uint32), oracle.math("log", u).view(np.uint32))
 
 
+def test_k1_rng_vectors_on_the_device(renderer_mod):
+    """the RNG known-answer vectors of SURVEY.md §8(c) (frag.glsl:686-694) through the DEVICE's NextRandom / random(), not only the oracle's"""
+    from test_oracle_kat import RNG_KAT
+    r = renderer_mod.Renderer(64, 64)
+    for start, rows in RNG_KAT.items():
+        st = np.array([start], dtype=np.uint32)
+        for exp_state, exp_res, exp_bits in rows:
+            res = r.debug_math("rng_result", st.view(np.float32)).view(np.uint32)
+            rnd = r.debug_math("rng_random", st.view(np.float32)).view(np.uint32)
+            st = r.debug_math("rng_state", st.view(np.float32)).view(np.uint32).copy()
+            assert (int(st[0]), int(res[0]), int(rnd[0])) == (exp_state, exp_res, exp_bits)
+    r.close()
+
+
 @pytest.mark.parametrize("name,W,H", [("C2", 96, 54), ("C3", 96, 54), ("C1", 64, 64)])
 def test_intersect_parity(pt, oracle, renderer_mod, name, W, H):
     wl = pt.scenes.build(name, W, H)
