@@ -12,12 +12,18 @@ extern "C" {
 
 /* Tuning knobs: 0 = path slots in flight (default 0 = automatic: one per job of a synchronous batch within [2^20, 2^22]; 5/8 of the
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
- * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once), 4 = intersect kernel (0 simple, 1 persistent),
+ * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once),
+ * 4 = intersect kernel (0 simple, one block per 256 rays; 1 persistent blocks, compiled; 2 = default: the hand-written form of 1, csrc/hip/pt_extend_gfx950.s,
+ *     for the launches it takes — no ellipsoids, at most 8 BVHs, no empty leaves, ordered boxes, RAYTRACING == 1, statistics off — and 1 for the others),
  * 5 = persistent block size (64/128/256/512/1024, default 256), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on the blocks per CU of the persistent grid (default 0 = no cap: as many as are resident at once, 8 blocks of 256 threads = 8 waves per SIMD),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6),
  * 10 = inner-node records kept in breadth-first order (whole levels, the top of the trees); deeper ones are laid out depth-first,
- * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 32-bit; -1 = automatic */
+ * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 32-bit; -1 = automatic.
+ * 14 = main loop of the hand-written intersect kernel: -1 automatic (default), 0 phase-voting like the compiled kernel, 1 fused trip (every lane on a node or
+ *      a leaf advances each trip; a lane's record is requested the moment its entry is decided).
+ * Queries (tests): 12 = PT_OK iff the current scene runs on the hand-written intersect kernel (else PT_ERR_UNSUPPORTED and the reason in pt_last_error),
+ * 13 = PT_OK iff that kernel has been launched more than `value` times by this context. */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
 
 /* Per-kernel device time since pt_set_timing(1) / pt_reset_counters, measured with HIP events on the
@@ -33,9 +39,10 @@ int pt_debug_phase_stats(pt_ctx* ctx, uint64_t* out, int n);
 int pt_kernel_time_median(pt_ctx* ctx, int kernel, double* median_ms);
 
 /* Debug / parity probes (used by tests): evaluates the device numeric contract.
- * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; host pointers, n elements. */
+ * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; 6 / 7 / 8 = the state after / the result of / random() of ONE NextRandom call
+ * (frag.glsl:686-694), the uint32 state passed as float bits; host pointers, n elements. */
 int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, size_t n);
-/* Single rays through the intersect kernel: o,d are n*3 f32 (host); out is n*4 f32 (t,u,v) + prim as int bits */
+/* Single rays through the intersect kernel option 4 selects (the production kernels included): o,d are n*3 f32 (host); out is n*4 f32 (t,u,v) + prim as int bits */
 int pt_debug_intersect(pt_ctx* ctx, const float* o, const float* d, float* out, size_t n);
 
 #ifdef __cplusplus

@@ -832,9 +832,18 @@ struct pt_ctx {
     // options / stats
     bool countStats = false, timing = false;
     int ldsBudget = 20 * 1024;
-    int extendMode = 1;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist)
+    int extendMode = 2;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist), 2: the hand-written form of 1
+                                    //    (pt_extend_gfx950.s) for the scenes it takes, 1 for the others
+    float* dNodes80 = nullptr;      // node records of the hand-written kernel: 80 B, (min pair, max pair, min pair) per axis + the two references
+    void* dAsmDbg = nullptr;
+    std::string asmError;           // a failed load / launch of the hand-written kernel (surfaces as PT_ERR_HIP from the render call)
+    uint64_t asmLaunches = 0;
+    bool asmEligible = false;       // this scene can run on the hand-written kernel (buildScene)
+    std::string asmWhyNot;          // ... or why not (pt_debug: reported by option 12)
+    hipModule_t asmModule = nullptr, asmModule2 = nullptr; hipFunction_t asmFn[2] = {nullptr, nullptr};      // [0] 16-bit stack entries, [1] Packed18
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
     int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
+    int asmLoop = -1;               // hand-written kernel's main loop: -1 automatic, 0 phase-voting, 1 fused trip (pt_set_option 14)
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
     int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 0; int innerKeepEighths = 6;
     int bfsNodes = 0x7fffffff;      // inner-node records kept in breadth-first order (whole levels); the rest follow depth-first (buildScene)
@@ -1008,7 +1017,23 @@ int buildScene(pt_ctx* c) {
         nodeRecs.push_back(f4(A[0], B[0], A[1], B[1])); nodeRecs.push_back(f4(A[2], B[2], A[3], B[3])); nodeRecs.push_back(f4(A[4], B[4], A[5], B[5]));
         nodeRecs.push_back(f4(asf((uint32_t)refOf(L)), asf((uint32_t)refOf(R)), 0, 0));
     }
-    std::vector<ObjRoot> roots(std::max(numObj, 1));
+    // The hand-written intersect kernel (pt_extend_gfx950.s) reads 80-B node records: per axis (Lmin, Rmin | Lmax, Rmax | Lmin, Rmin), so that
+    // a lane whose direction component is negative starts 8 B further in and receives (near pair, far pair); then the two references.
+    std::vector<float> nodes80(std::max<size_t>(order.size(), 1) * 20, 0.0f);
+    bool boxesOrdered = true, anyEmpty = false;
+    for (size_t k = 0; k < order.size(); k++) {
+        const int n = order[k], L = childOf(n, 0), R = childOf(n, 1);
+        const float* A = c->bvhdata.data() + 8 * (size_t)L; const float* B = c->bvhdata.data() + 8 * (size_t)R;
+        float* o = nodes80.data() + 20 * k;
+        for (int ax = 0; ax < 3; ax++) {
+            o[6 * ax] = A[ax]; o[6 * ax + 1] = B[ax]; o[6 * ax + 2] = A[3 + ax]; o[6 * ax + 3] = B[3 + ax]; o[6 * ax + 4] = A[ax]; o[6 * ax + 5] = B[ax];
+            if (!(A[ax] <= A[3 + ax]) || !(B[ax] <= B[3 + ax])) boxesOrdered = false;      // min > max or a NaN: only the min/max form of rayBox is right
+        }
+        const int lr = refOf(L), rr = refOf(R);
+        std::memcpy(&o[18], &lr, 4); std::memcpy(&o[19], &rr, 4);
+        if (lr == REF_EMPTY || rr == REF_EMPTY) anyEmpty = true;
+    }
+    std::vector<ObjRoot> roots(std::max(numObj, 8));           // (the hand-written kernel fetches root records in batches of four: at least eight exist)
     for (int o = 0; o < numObj; o++) {
         int r = c->objidx[1 + o]; const float* A = c->bvhdata.data() + 8 * (size_t)r;
         for (int k = 0; k < 3; k++) { roots[o].bmin[k] = A[k]; roots[o].bmax[k] = A[3 + k]; }
@@ -1040,6 +1065,7 @@ int buildScene(pt_ctx* c) {
     HIP_TRY(hipStreamSynchronize(s));
     int rc;
     if ((rc = uploadVec((void**)&c->dNodes, nodeRecs.data(), nodeRecs.size() * 16, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dNodes80, nodes80.data(), nodes80.size() * 4, s))) return rc;
     if ((rc = uploadVec((void**)&c->dTris, triRecs.data(), triRecs.size() * 16, s))) return rc;
     if ((rc = uploadVec((void**)&c->dShade, shade.data(), shade.size() * 16, s))) return rc;
     if ((rc = uploadVec((void**)&c->dTriObj, triObj.data(), triObj.size() * 4, s))) return rc;
@@ -1090,6 +1116,16 @@ int buildScene(pt_ctx* c) {
         int pt_ = (pn == sc.nNodes) ? std::min(sc.nTriRecs, (cb - pn * 64) / 48) : 0;
         c->pLdsNodes = pn; c->pLdsTris = pt_;
     }
+    // which scenes the hand-written kernel takes (the others run on the compiled k_extend_persist, same results)
+    for (int o = 0; o < numObj; o++) if (roots[o].ref == REF_EMPTY) anyEmpty = true;
+    c->asmWhyNot.clear();
+    if (nE > 0) c->asmWhyNot = "ellipsoids";
+    else if (numObj < 1 || numObj > 8) c->asmWhyNot = "no BVH or more than 8";
+    else if (anyEmpty) c->asmWhyNot = "a leaf without triangles";
+    else if (!boxesOrdered) c->asmWhyNot = "a node box with min > max or a NaN";
+    else if (c->stackMode == 2) c->asmWhyNot = "tree too large for 18-bit stack entries";
+    else if (triRecs.size() / 3 >= (1u << 24) || order.size() >= (1u << 24)) c->asmWhyNot = "more than 2^24 records";
+    c->asmEligible = c->asmWhyNot.empty();
     c->sceneDirty = false;
     return 0;
 }
@@ -1147,7 +1183,80 @@ void launchEP(pt_ctx* c, const PoolRun& pr, const DevScene& sc, size_t lds, int 
     hipLaunchKernelGGL((k_extend_persist<COUNT, StackT, TPB, false>), dim3(grid), dim3(TPB), lds, pr.stream, sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl, c->refillMin,
                        c->innerKeepEighths, nObjLds, c->noneMin);
 }
+// Kernel arguments of pt_extend_gfx950.s (offsets are written into the assembly)
+struct EpAsmArgs {
+    const void *nodes80, *tris, *roots, *G0, *G1; void* H; const unsigned* queue; Control* ctl;
+    int ldsNodes, ldsTris, numObj, iter, nSlots, refillMin, keepEighths, noneMin;
+    unsigned divM, divS, nWaves, mode;      // mode: 1 the fused trip, 0 the phase-voting loop
+    void* dbg;                      // developer builds of the assembly (-DPT_ASM_DEBUG): 32 B per wave
+};
+static_assert(sizeof(EpAsmArgs) == 120, "EpAsmArgs layout is part of the assembly");
+#ifndef PT_EXTEND_INC
+#define PT_EXTEND_INC "pt_extend_hsaco.inc"
+#endif
+#include PT_EXTEND_INC              // the assembled code objects (build.py): pt_extend_hsaco_s16[], pt_extend_hsaco_p18[]
+
+int loadAsmKernel(pt_ctx* c) {
+    if (c->asmFn[0]) return 0;
+    hipModule_t m0 = nullptr, m1 = nullptr;
+    HIP_TRY(hipModuleLoadData(&m0, pt_extend_hsaco_s16));
+    HIP_TRY(hipModuleLoadData(&m1, pt_extend_hsaco_p18));
+    HIP_TRY(hipModuleGetFunction(&c->asmFn[0], m0, "pt_extend_asm"));
+    HIP_TRY(hipModuleGetFunction(&c->asmFn[1], m1, "pt_extend_asm"));
+    c->asmModule = m0; c->asmModule2 = m1;
+    return 0;
+}
+
+// true: launched.  false: this launch is not one the hand-written kernel takes (the caller uses the compiled kernel)
+bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
+    if (!c->asmEligible || c->countStats || c->streamIn.params[9] != 1.0f || c->ellipMaps || c->extendTpb != 256) return false;
+    const DevScene& sc = c->sc;
+    const size_t fixed = (size_t)sc.numObj * 1024 + 32 + (size_t)c->stackDepth * 512;
+    if (fixed + 2048 > 64 * 1024) return false;
+    size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, 64 * 1024 - fixed);
+    {   // the node tile gives way to residency, as in launchExtendPersist
+        const int want = c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : 8;
+        const size_t perBlock = (size_t)160 * 1024 / (size_t)want;
+        if (fixed + cb + 16 > perBlock && perBlock > fixed + 16 + 2048) cb = std::min(cb, (perBlock - fixed - 16) & ~(size_t)15);
+    }
+    EpAsmArgs a{};
+    a.ldsNodes = (int)std::min<size_t>((size_t)sc.nNodes, cb / 80);
+    a.ldsTris = (a.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)a.ldsNodes * 80) / 48) : 0;
+    size_t lds = (size_t)a.ldsNodes * 80 + (size_t)a.ldsTris * 48 + fixed;
+    lds = (lds + 15) & ~(size_t)15;
+    int perCU = std::max(1, std::min((int)(160 * 1024 / lds), 8));
+    if (c->extendMaxBlocksPerCU > 0) perCU = std::min(perCU, c->extendMaxBlocksPerCU);
+    int grid = c->numCUs * perCU;
+    grid = std::max(1, std::min(grid, ((int)pr.launched + 255) / 256));
+    if (loadAsmKernel(c)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
+    a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
+    a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
+    a.numObj = sc.numObj; a.iter = pr.iter; a.nSlots = (int)pr.launched; a.refillMin = c->refillMin; a.keepEighths = c->innerKeepEighths; a.noneMin = c->noneMin;
+    // main loop: the fused trip with fetch-at-decision, unless the whole scene sits in the LDS tile — then no fetch is worth hiding and the
+    // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)
+    const bool allInLds = a.ldsNodes == sc.nNodes && a.ldsTris == sc.nTriRecs;
+    a.mode = c->asmLoop >= 0 ? (unsigned)c->asmLoop : (allInLds ? 0u : 1u);
+    a.nWaves = (unsigned)grid * 4u;
+    if (getenv("PT_ASM_DEBUG")) {
+        if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 32) != hipSuccess) return false; }
+        hipMemsetAsync(c->dAsmDbg, 0xff, 8192 * 32, pr.stream);
+        a.dbg = c->dAsmDbg;
+    }
+    {   // x / nWaves == mulhi(x, divM) >> divS for x < 2^31 (nWaves >= 4)
+        unsigned d = a.nWaves; int l = 0;
+        while ((1ull << l) < d) l++;
+        a.divM = (unsigned)(((1ull << (31 + l)) + d - 1) / d); a.divS = (unsigned)(l - 1);
+    }
+    size_t asz = sizeof(a);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    const hipError_t e = hipModuleLaunchKernel(c->asmFn[c->stackMode == 1 ? 1 : 0], (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
+    if (e != hipSuccess) { c->asmError = std::string("hipModuleLaunchKernel(pt_extend_asm): ") + hipGetErrorString(e); return false; }
+    c->asmLaunches++;
+    return true;
+}
+
 void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
+    if (c->extendMode == 2 && launchExtendAsm(c, pr)) return;
     const int launched = (int)pr.launched;
     DevScene sc = c->sc;
     int tpb = c->extendTpb;
@@ -1281,6 +1390,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             iters++;
         }
         HIP_TRY(hipGetLastError());                                // a failed launch surfaces here, not as "did not drain"
+        if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
         // has the oldest batch been handed out completely (as of the previous look)?  then see whether it is still in flight
         const bool scan = !c->pending.empty() && c->lastNextJob >= c->pending.front().jobEnd;
         if (scan) {
@@ -1582,7 +1692,9 @@ int pt_destroy(pt_ctx* c) {
     hipSetDevice(c->device);
     flushStream(c);
     hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
+    if (c->asmModule) hipModuleUnload(c->asmModule);
+    if (c->asmModule2) hipModuleUnload(c->asmModule2);
+    void* ptrs[] = {c->dNodes80, c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hCtl) hipHostFree(c->hCtl);
@@ -1855,7 +1967,13 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 1: c->countStats = value != 0; return PT_OK;
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
         case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; return PT_OK;
-        case 4: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "extend mode must be 0 or 1"); c->extendMode = (int)value; return PT_OK;
+        case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
+        case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
+        case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)
+        case 12: {                                                // query (debug): 0 = the current scene runs on the hand-written intersect kernel, else PT_ERR_UNSUPPORTED + why not
+            if (c->sceneDirty) { int rc = buildScene(c); if (rc) return rc; }
+            return c->asmEligible ? PT_OK : fail(PT_ERR_UNSUPPORTED, "compiled intersect kernel: " + c->asmWhyNot);
+        }
         case 5: if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 64, 128, 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
         case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
@@ -1912,6 +2030,10 @@ int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
     Control h;
     HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < n && k < 16; k++) out[k] = h.dbg[k];
+    if (c->dAsmDbg && n >= 16 + 8192 * 4) {                       // developer builds of the hand-written kernel (-DPT_ASM_DEBUG / -DPT_ASM_PROF): 8 words per wave of the last launch
+        HIP_TRY(hipMemcpy(out + 16, c->dAsmDbg, 8192 * 32, hipMemcpyDeviceToHost));
+        return PT_OK;
+    }
 #if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     for (int k = 16; k < n && k < 16 + 8192; k++) out[k] = h.waveEnd[k - 16];
     for (int k = 16 + 8192; k < n && k < 16 + 2 * 8192; k++) out[k] = h.waveStart[k - 16 - 8192];
@@ -1988,7 +2110,7 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     Scratch scratch{{(void**)&st.G0, (void**)&st.G1, (void**)&st.H}};  // freed on every return path
     HIP_TRY(hipMalloc((void**)&st.G0, np * 16)); HIP_TRY(hipMalloc((void**)&st.G1, np * 16)); HIP_TRY(hipMalloc((void**)&st.H, np * 16));
     HIP_TRY(hipMemcpy(st.G0, g0.data(), np * 16, hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(st.G1, g1.data(), np * 16, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(st.H, 0, np * 16));
+    HIP_TRY(hipMemsetAsync(st.H, 0, np * 16, c->stream));       // ordered before the kernels below (the context's stream does not wait for the null stream)
     // the ellipsoid rotation matrices are produced by k_frame_setup
     FrameIn fin; std::memset(&fin, 0, sizeof(fin));
     if (c->params.size() >= 12) std::memcpy(fin.params, c->params.data(), 48);
@@ -1997,10 +2119,24 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, c->stream, c->sc, c->dFrameIn, c->dFc, c->dEllip);
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
     hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, c->stream, c->dCtl);
-    hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, 0, (int)np, c->dCtl);
+    if (c->extendMode == 0) {
+        hipLaunchKernelGGL(k_extend<false>, dim3((unsigned)(np / BLOCK)), dim3(BLOCK), ldsBytes, c->stream, c->sc, st, (const unsigned*)nullptr, 0, (int)np, c->dCtl);
+    } else {                                                      // the production kernels (persistent blocks; hand-written or compiled), as pump() launches them
+        std::memcpy(c->streamIn.params, fin.params, 48); c->streamIn.params[9] = 1.0f;      // no thickness probes in this pool
+        PoolRun pr; pr.stream = c->stream; pr.st = st; pr.launched = (unsigned)np; pr.iter = 0;
+        launchExtendPersist(c, pr);
+        std::memset(&c->streamIn, 0xff, sizeof(FrameIn));
+    }
+    HIP_TRY(hipGetLastError());
+    if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> h(np * 4);
     HIP_TRY(hipMemcpy(h.data(), st.H, np * 16, hipMemcpyDeviceToHost));
+    if (c->dAsmDbg && getenv("PT_ASM_DEBUG")) {
+        std::vector<unsigned> dbg(8192 * 8);
+        HIP_TRY(hipMemcpy(dbg.data(), c->dAsmDbg, dbg.size() * 4, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 24; w++) { fprintf(stderr, "asm wave %d:", w); for (int k = 0; k < 8; k++) fprintf(stderr, " %u", dbg[8 * w + k]); fprintf(stderr, "\n"); }
+    }
     std::memcpy(out, h.data(), n * 16);
     return PT_OK;
 }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Where a wave of the hand-written intersect kernel spends its cycles (needs a -DPT_ASM_DEBUG -DPT_ASM_PROF -DPARK=0 build: PT_HIP_LIB, and
+PT_ASM_DEBUG=1 in the environment): asm_prof.py [config] [frames] [option=value ...] -> per-wave accumulators of the LAST intersect launch."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ptimport  # noqa: E402
+
+pt = ptimport.load()
+from pathtracer_0_amd import renderer, scenes  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+W, H = 1920, 1080
+wl = scenes.build(name, W, H)
+r = renderer.Renderer(W, H)
+r.load_workload(wl); r.reset_frame(); r.set_option("path_slots", 1 << 23)
+for kv in sys.argv[3:]:
+    k, v = kv.split("="); r.set_option(k, int(v)); print("option", k, v)
+# stop in the steady state: the last launch before the poll is a full one
+r.render_batch_async(1, [scenes.frame_seed(f) for f in range(1, frames + 1)])
+out = np.zeros(16 + 8192 * 4, np.uint64)
+L = renderer.lib(); L.pt_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+L.pt_debug_phase_stats(r._h, out.ctypes.data, out.size)
+w = out[16:].view(np.uint32).reshape(8192, 8)
+w = w[w[:, 0] != 0xffffffff]
+names = ("votes+rest", "node fetch wait", "node step", "tri fetch wait", "tri step", "next BVH/retire", "refill")
+tot = w[:, :7].astype(np.float64).sum()
+print(name, "waves", len(w), "cycles per wave %.0f" % (tot / max(len(w), 1)), "node steps per wave %.1f" % w[:, 7].mean())
+for k, nm in enumerate(names):
+    print(f"  {nm:18s} {100 * w[:, k].astype(np.float64).sum() / tot:5.1f} %   per node step: {w[:, k].astype(np.float64).sum() / max(w[:, 7].sum(), 1):7.1f} cycles")
+r.synchronize(); r.close()

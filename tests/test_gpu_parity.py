@@ -86,8 +86,18 @@ def test_k1_rng_vectors_on_the_device(renderer_mod):
     r.close()
 
 
+def asm_taken(r):
+    """does this context's scene run on the hand-written intersect kernel (pt_extend_gfx950.s)?"""
+    try:
+        r.set_option("query_asm_eligible", 0)
+        return True
+    except Exception:
+        return False
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("name,W,H", [("C2", 96, 54), ("C3", 96, 54), ("C1", 64, 64)])
-def test_intersect_parity(pt, oracle, renderer_mod, name, W, H):
+def test_intersect_parity(pt, oracle, renderer_mod, name, W, H, mode):
     wl = pt.scenes.build(name, W, H)
     rs = np.random.RandomState(3)
     n = 4096
@@ -97,7 +107,12 @@ def test_intersect_parity(pt, oracle, renderer_mod, name, W, H):
     d[:4] = [[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 0, 0]]
     r = renderer_mod.Renderer(W, H)
     r.load_workload(wl)
+    r.set_option("extend_mode", mode)          # 0: one block per 256 rays; 1: persistent, compiled; 2: persistent, hand-written (C1 has ellipsoids: compiled)
     tuv, prim = r.debug_intersect(o, d)
+    if mode == 2:
+        assert asm_taken(r) == (name != "C1")
+        if name != "C1":
+            r.set_option("query_asm_launches_above", 0)
     r.close()
     sc = oracle.Scene.from_workload(wl)
     for i in range(n):
@@ -154,8 +169,12 @@ def test_nan_slab_rays(pt, oracle, renderer_mod):
     assert (a_ieee != a_spec).sum() > 100, "the ray set must contain boxes on which minNum and the specification's min/max differ"
     r = renderer_mod.Renderer(96, 54)
     r.load_workload(wl)
-    tuv, prim = r.debug_intersect(O, D)
+    tuv, prim = r.debug_intersect(O, D)         # the hand-written kernel: these rays are the ones that switch it to the min/max form of rayBox
+    r.set_option("query_asm_launches_above", 0)
+    r.set_option("extend_mode", 1)
+    tuv1, prim1 = r.debug_intersect(O, D)
     r.close()
+    assert np.array_equal(prim, prim1) and np.array_equal(tuv.view(np.uint32), tuv1.view(np.uint32))
     sc = oracle.Scene.from_workload(wl)
     hits = 0
     for i in range(len(O)):
@@ -172,6 +191,71 @@ def test_nan_slab_rays(pt, oracle, renderer_mod):
     wl2 = pt.scenes.Workload("C2_grazing", wl2.W, wl2.H, b, wl2.sky, wl2.sample_res, wl2.max_bounces, wl2.info)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl2, 2)
     assert_same(got, ref, cnt, ocnt)
+    got, ref, _, _ = render_both(pt, oracle, renderer_mod, wl2, 2, count_stats=False)     # ... and on the hand-written kernel (statistics run on the compiled one)
+    assert_same(got, ref)
+
+
+def mixed_regular_and_axis_parallel_rays(wl, n, seed):
+    rs = np.random.RandomState(seed)
+    o = (np.array(wl.buffers[0]) + rs.normal(scale=0.4, size=(n, 3))).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    k = rs.randint(0, n, size=n // 16)                     # every wave gets a few rays with a zero / negative-zero / NaN / infinite component
+    d[k, rs.randint(0, 3, size=k.size)] = rs.choice(np.array([0.0, -0.0, np.nan, np.inf, 1e-42], np.float32), size=k.size)
+    k = rs.randint(0, n, size=n // 64)
+    o[k, rs.randint(0, 3, size=k.size)] = rs.choice(np.array([np.inf, np.nan, 1.0, -1.0, 0.0], np.float32), size=k.size)
+    return o, d
+
+
+@pytest.mark.parametrize("name,W,H,kw,opts", [("C2", 96, 54, {}, {}), ("C2", 96, 54, {}, {"asm_loop": 1}), ("C3", 96, 54, {}, {}), ("C3", 96, 54, {}, {"asm_loop": 0}),
+                                              ("C4", 64, 36, {}, {"asm_loop": 0}), ("C3", 96, 54, {}, {"extend_cache_bytes": 0, "refill_min": 1}),
+                                              ("C3", 96, 54, {}, {"extend_cache_bytes": 60000, "refill_min": 64, "none_min": 1}),
+                                              ("C5", 64, 36, {"subdiv": 2}, {"inner_keep_eighths": 0}), ("C4", 64, 36, {}, {}), ("C5", 64, 36, {}, {"stack_mode": 1})])
+def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
+    """pt_extend_gfx950.s against the compiled kernels on 64 K rays per scene, a sixteenth of them irregular (zero, denormal, infinite, NaN
+    components: the rays that take its min/max step): every hit record bit for bit.  C4 and the last case run its 18-bit-stack form;
+    asm_loop picks its main loop (0 phase-voting, 1 fused trip; automatic: fused unless the whole scene sits in the LDS tile, as C2 does)."""
+    wl = pt.scenes.build(name, W, H, **kw)
+    o, d = mixed_regular_and_axis_parallel_rays(wl, 1 << 16, 11)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl)
+    for k, v in opts.items():
+        r.set_option(k, v)
+    assert asm_taken(r)
+    out = {}
+    for mode in (2, 1, 0):
+        r.set_option("extend_mode", mode)
+        tuv, prim = r.debug_intersect(o, d)
+        out[mode] = (tuv.view(np.uint32).copy(), prim.copy())
+    r.set_option("query_asm_launches_above", 0)
+    r.close()
+    for mode in (1, 0):
+        same = (out[2][1] == out[mode][1]) & (out[2][0] == out[mode][0]).all(axis=1)
+        assert same.all(), (mode, int((~same).sum()), np.nonzero(~same)[0][:8], out[2][1][~same][:8], out[mode][1][~same][:8])
+    assert (out[2][1] >= 0).sum() > 1000
+
+
+@pytest.mark.parametrize("name,W,H,frames,kw,opts", [("C2", 96, 54, 3, {}, {}), ("C3", 128, 72, 3, {}, {}), ("C3", 128, 72, 4, {}, {"path_slots": 2048}),
+                                                     ("C3", 128, 72, 2, {}, {"path_slots": 1 << 16, "refill_min": 8}), ("C5", 64, 36, 2, {"subdiv": 2}, {}),
+                                                     ("C4", 64, 36, 2, {}, {}), ("T1", 96, 54, 2, {}, {}), ("C3", 128, 72, 3, {}, {"asm_loop": 0}),
+                                                     ("C2", 96, 54, 2, {}, {"asm_loop": 1, "path_slots": 1024})])
+def test_render_parity_handwritten_kernel(pt, oracle, renderer_mod, name, W, H, frames, kw, opts):
+    """whole renders on the hand-written intersect kernel (statistics off: the counting variant is the compiled kernel) against the oracle,
+    including the small pool that hands over to the device-packed tail queue"""
+    wl = pt.scenes.build(name, W, H, **kw)
+    seeds = seeds_for(pt, 1, frames)
+    r = renderer_mod.Renderer(W, H)
+    for k, v in opts.items():
+        r.set_option(k, v)
+    r.load_workload(wl)
+    r.reset_frame()
+    r.render_batch(1, seeds)
+    got = r.read_frame()
+    assert asm_taken(r)
+    r.set_option("query_asm_launches_above", 3)
+    r.close()
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, frames, seeds, nthreads=8)
+    assert_same(got, ref)
 
 
 @pytest.mark.parametrize("mode", [0, 1])
