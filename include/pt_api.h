@@ -135,6 +135,12 @@ int pt_read_frame(pt_ctx* ctx, float* rgba_out);
  * signed-byte packing of :819-822 when java_bytes != 0 (a channel >= 128 borrows 1 from the channel above it), vertical flip
  * (:828-833).  rgb_out: width*height*3 bytes, top row first.  Needs the whole image: a one-GPU or a multi-GPU context.  Synchronises. */
 int pt_read_display(pt_ctx* ctx, int frame_count, int java_bytes, uint8_t* rgb_out);
+/* ... and the file functions.screenshot writes (dispatch.java:840-848: ImageIO.write(imageOut, "PNG", file)): the pixels of pt_read_display
+ * as an 8-bit RGB PNG at `path` (the directory must exist; the reference creates "screenshots/").  The pixel values are the reference's; the
+ * file's bytes are not ImageIO's (a PNG encoder is free in its compression: this one stores the scanlines uncompressed), and the Java2D
+ * bilinear AffineTransformOp the reference flips with (:828-833) copies rows exactly except for JRE-specific edge handling, which is not
+ * restated.  Synchronises. */
+int pt_save_png(pt_ctx* ctx, int frame_count, int java_bytes, const char* path);
 
 /* Device-resident accumulator of this shard: n_pixels RGBA32F in shard-local pixel order
  * (shard_count == 1: plain row-major FRAME).  Valid until pt_destroy. */

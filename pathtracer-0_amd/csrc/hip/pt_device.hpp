@@ -273,13 +273,15 @@ PM_DEV uint32_t NextRandom(uint32_t& state) {
     return result;
 }
 PM_DEV float random_(uint32_t& state) { return (float)NextRandom(state) / 4294967295.0f; }
+template <bool FAST = false>
 PM_DEV float randValNormalDist(uint32_t& st) {
-    float theta = 2.0f * 3.1415926f * random_(st);
-    float rho = __builtin_sqrtf(-2.0f * log_(random_(st)));
-    return rho * cos_(theta);
+    const float u1 = random_(st);                  // theta's draw first, then rho's (:697-698)
+    const float u2 = random_(st);
+    return boxMullerT<FAST>(u1, u2);
 }
+template <bool FAST = false>
 PM_DEV vec3 randLambertianDistVec(uint32_t& st) {
-    float x = randValNormalDist(st), y = randValNormalDist(st), z = randValNormalDist(st);
+    float x = randValNormalDist<FAST>(st), y = randValNormalDist<FAST>(st), z = randValNormalDist<FAST>(st);
     return v3(x, y, z);
 }
 
@@ -398,15 +400,16 @@ PM_DEV vec3 bgCol(const DevScene& sc, vec3 In) {
     return sampleSky(sc, u, v);
 }
 
+template <bool FAST = false>
 PM_DEV float fresnelReflectAmount(float n1, float n2, vec3 normal, vec3 incidence) {
-    float r0 = (n1 - n2) / (n1 + n2);
+    float r0 = divT<FAST>(n1 - n2, n1 + n2);
     r0 *= r0;
     float cosX = -dot(normal, incidence);
     if (n1 > n2) {
-        float n = n1 / n2;
+        float n = divT<FAST>(n1, n2);
         float sinT2 = n * n * (1.0f - cosX * cosX);
         if (sinT2 > 1.0f) return 1.0f;
-        cosX = __builtin_sqrtf(1.0f - sinT2);
+        cosX = sqrtT<FAST>(1.0f - sinT2);
     }
     float x = 1.0f - cosX;
     return r0 + (1.0f - r0) * x * x * x * x * x;
@@ -417,6 +420,7 @@ PM_DEV float fresnelReflectAmount(float n1, float n2, vec3 normal, vec3 incidenc
 // shading kernel is VALU-issue bound).  chooseLobe = weights + roll (+ the subsurface draw) -> winType;
 // lobeDirection = the out direction for that winType from the already drawn Gaussian vector G.
 // RNG draw order is the reference's: roll, [subsurface draw], 6 Gaussian draws (none for transmission).
+template <bool FAST = false>
 PM_DEV int chooseLobe(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint32_t& rng) {
     float reflectionWeight = 1.0f - m.Pr;
     float clearcoatWeight = m.Pc;
@@ -424,13 +428,14 @@ PM_DEV int chooseLobe(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint3
     float subsurfaceWeight = m.subsurface;
     float fresnel = 0.0f;
     if (m.illum == 5 || m.illum == 7 || transmissionWeight > 0.0f) {
-        fresnel = fresnelReflectAmount(n1, n2, N, D);
+        fresnel = fresnelReflectAmount<FAST>(n1, n2, N, D);
         reflectionWeight += fresnel * m.Pr;
         transmissionWeight *= (1.0f - fresnel);
     }
     float diffuseWeight = (1.0f - m.Pm) * (1.0f - transmissionWeight) * (1.0f - fresnel);
     float totalWeight = diffuseWeight + reflectionWeight + clearcoatWeight + transmissionWeight;
-    reflectionWeight /= totalWeight; clearcoatWeight /= totalWeight; transmissionWeight /= totalWeight;
+    if (FAST) { const float inv = __builtin_amdgcn_rcpf(totalWeight); reflectionWeight *= inv; clearcoatWeight *= inv; transmissionWeight *= inv; }
+    else { reflectionWeight /= totalWeight; clearcoatWeight /= totalWeight; transmissionWeight /= totalWeight; }
     float roll = random_(rng);
     if (roll < reflectionWeight) return 1;
     if (roll < reflectionWeight + clearcoatWeight) return 2;
@@ -438,22 +443,24 @@ PM_DEV int chooseLobe(const MatRec& m, float n1, float n2, vec3 N, vec3 D, uint3
     if (subsurfaceWeight > 0.0f) { if (random_(rng) < subsurfaceWeight) return 4; }
     return 0;
 }
+template <bool FAST = false>
 PM_DEV vec3 lobeDirection(int w, vec3 G, vec3 N, vec3 D, float eta, float Pcr) {
-    if (w == 3) return refract(D, N, eta);                                        // :783
-    vec3 rough = normalize(G + N);
+    if (w == 3) return refractT<FAST>(D, N, eta);                                 // :783
+    vec3 rough = normalizeT<FAST>(G + N);
     if (w == 1 || w == 2) return mix(reflect(D, N), rough, w == 1 ? 0.0f : Pcr);  // :775 (Q-8), :779
     return rough;                                                                 // :795-804
 }
 
 // Camera ray of one sample, main() frag.glsl:894-908, for global pixel (px,py): lens jitter (6 RNG draws), focus, normalise.
+template <bool FAST = false>
 PM_DEV void cameraRay(const FrameConst& fc, int W, int H, int px, int py, uint32_t& rng, vec3& O, vec3& D) {
     float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
     vec3 q = v3(((tcx * 2.0f - 1.0f) * -1.0f) * fc.screenSize, ((tcy * 2.0f - 1.0f) * fc.screenHratio) * fc.screenSize, fc.focalLength);
     vec3 direction = vecmat(q, fc.camRot);
     vec3 ORIGIN = v3(fc.origin[0], fc.origin[1], fc.origin[2]);
-    vec3 origin_jittered = ORIGIN + vecmat(randLambertianDistVec(rng) * fc.BLUR, fc.camRot);
+    vec3 origin_jittered = ORIGIN + vecmat(randLambertianDistVec<FAST>(rng) * fc.BLUR, fc.camRot);
     vec3 focal_point = ORIGIN + direction * fc.focus;
-    D = normalize(focal_point - origin_jittered);
+    D = normalizeT<FAST>(focal_point - origin_jittered);
     O = origin_jittered;
 }
 // trace() prologue (:811-818): everything a new sample resets that needs no random numbers
@@ -465,8 +472,9 @@ PM_DEV void tracePrologue(Path& p) {
     p.bounce = 0;
     p.probe = false; p.probeObj = 0;
 }
+template <bool FAST = false>
 PM_DEV void startSample(const FrameConst& fc, int W, int H, int px, int py, Path& p) {
-    cameraRay(fc, W, H, px, py, p.rng, p.O, p.D);
+    cameraRay<FAST>(fc, W, H, px, py, p.rng, p.O, p.D);
     tracePrologue(p);
 }
 
@@ -484,7 +492,7 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
 
 // One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
 // Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
-template <bool TRANS, bool TEX>
+template <bool TRANS, bool TEX, bool FAST = false>
 PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, const float4* HX, unsigned slot) {
     p.bounce++;                                               // :821
     const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
@@ -499,13 +507,13 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
         if (prim & PRIM_ELLIPSOID) {
             const EllipRec& E = sc.ellip[prim & 0xffffff];
             vec3 c = v3(E.c[0], E.c[1], E.c[2]);
-            if (E.rotated) N = normalize(vecmat(loc - c, E.RB)); else N = normalize(loc - c);     // :622-626
+            if (E.rotated) N = normalizeT<FAST>(vecmat(loc - c, E.RB)); else N = normalizeT<FAST>(loc - c);     // :622-626
             mat = E.mat;
         } else {
             const float4* S = sc.shade + 4 * (size_t)prim;
             float4 s0 = S[0], s1 = S[1], s2 = S[2];
             vec3 vn1 = v3(s0.x, s0.y, s0.z), vn2 = v3(s0.w, s1.x, s1.y);
-            if (vn1.x != 0.0f && vn1.y != 0.0f && vn1.z != 0.0f) N = normalize(vn2 * hu + vn2 * hv + vn1 * (1.0f - hu - hv));   // :501-504 (Q-3)
+            if (vn1.x != 0.0f && vn1.y != 0.0f && vn1.z != 0.0f) N = normalizeT<FAST>(vn2 * hu + vn2 * hv + vn1 * (1.0f - hu - hv));   // :501-504 (Q-3)
             else N = vn2;                                                                                              // :506 (Q-4)
             mat = __float_as_int(s2.w);
         }
@@ -522,32 +530,32 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
             if (ND < 0.0f) { addToIndiceStack(p, m.Ni); n1 = p.s[1]; n2 = p.s[0]; }           // :833-836
             else { n1 = p.s[0]; n2 = p.s[1]; removeFirstOfIndiceStack(p); }                    // :838-840
         }
-        w = chooseLobe(m, n1, n2, N, D, p.rng);               // :843 up to the lobe decision
+        w = chooseLobe<FAST>(m, n1, n2, N, D, p.rng);         // :843 up to the lobe decision
         Ke = v3(m.Ke[0], m.Ke[1], m.Ke[2]); albedoKd = v3(m.Kd[0], m.Kd[1], m.Kd[2]); albedoKs = v3(m.Ks[0], m.Ks[1], m.Ks[2]);
         Tf = v3(m.Tf[0], m.Tf[1], m.Tf[2]); Pcr = m.Pcr; Density = m.Density;
     }
     vec3 G = v3(0.0f);
-    if (hit && w != 3) G = randLambertianDistVec(p.rng);      // the single random-vector site of the shading stage
+    if (hit && w != 3) G = randLambertianDistVec<FAST>(p.rng);      // the single random-vector site of the shading stage
     if (!hit) {
         p.inc = p.inc + bgCol(sc, D) * p.col;                 // :877
         return true;
     }
-    p.D = lobeDirection(w, G, N, D, n1 / n2, Pcr);
+    p.D = lobeDirection<FAST>(w, G, N, D, divT<FAST>(n1, n2), Pcr);
     if (TRANS && w == 3) {                                    // :847-863
         if (!p.g5loaded) { float4 g5 = G5[slot]; p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; }   // only transmission touches it
         p.g5dirty = true;
         if (ND < 0.0f) {
-            if (p.inObj) { p.dist = distance(p.enter, p.O); p.applyAbs = true; }
+            if (p.inObj) { p.dist = lengthT<FAST>(p.enter - p.O); p.applyAbs = true; }
             p.inObj = true;
             p.enter = p.O;
         } else {
             p.inObj = false;
-            p.dist = distance(p.enter, p.O);
+            p.dist = lengthT<FAST>(p.enter - p.O);
             p.applyAbs = true;
         }
     }
     p.inc = p.inc + Ke * p.col;                               // :865
-    if (length(p.col) < 0.1f) return true;                    // :866
+    if (lengthT<FAST>(p.col) < 0.1f) return true;             // :866
     if (TRANS && p.applyAbs) {
         p.col = p.col * exp3((-Tf) * p.dist * Density);      // :868
         p.applyAbs = false;

@@ -178,7 +178,7 @@ __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, u
 
 // Every dead slot of the pool asks for a job (one scheduler atomic per block) and, if one is left, starts it: the start of
 // a frame stream (all slots dead) and the restart after the pool ran dry between two batches.
-template <bool TRANS>
+template <bool TRANS, bool FAST>
 __global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp, State st, int nSlots, Control* ctl) {
     __shared__ unsigned sCnt[BLOCK / 64], sBase;
     const unsigned mode = ctl->needRevive;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp
         const FrameConst& fc = *fcp;
         Path p;
         startJob(b, fc, i, p);
-        startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
+        startSample<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
         storePath(st, i, p, TRANS);
         st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
         return;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp
     const FrameConst& fc = *fcp;
     Path p;
     startJob(b, fc, job, p);
-    startSample(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
+    startSample<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
     storePath(st, i, p, TRANS);
     st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
 }
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 // ran one instruction stream each; once the kernel had become memory-bound the permuted accesses cost more than the
 // divergence saved: 2-4 % per step on C2-C5, profiles/; likewise the dense LDS-listed pass that used to compute the camera
 // rays of new samples for the whole block.)
-template <bool TRANS, bool STATS, bool DIRECT, bool TEX>
+template <bool TRANS, bool STATS, bool DIRECT, bool TEX, bool FAST = false>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
                                                  int nSlots, Control* ctl) {
     __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase;
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
         isProbe = DIRECT && p.probe;
         if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w), st.HX, i);      // RAYTRACING == 0 (frag.glsl:911-912)
-        else sampleDone = shadeSegment<TRANS, TEX>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i);
+        else sampleDone = shadeSegment<TRANS, TEX, FAST>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i);
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
             p.sample++;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         }
     }
     // ---- 5. a lane that starts a sample computes its camera ray itself (frag.glsl:899-908); every store stays in slot order
-    if (needStart) { tracePrologue(p); cameraRay(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p.rng, p.O, p.D); }
+    if (needStart) { tracePrologue(p); cameraRay<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p.rng, p.O, p.D); }
     if (live) {
         st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
         st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
@@ -840,9 +840,13 @@ struct pt_ctx {
     uint64_t asmLaunches = 0;
     bool asmEligible = false;       // this scene can run on the hand-written kernel (buildScene)
     std::string asmWhyNot;          // ... or why not (pt_debug: reported by option 12)
-    hipModule_t asmModule = nullptr, asmModule2 = nullptr; hipFunction_t asmFn[2] = {nullptr, nullptr};      // [0] 16-bit stack entries, [1] Packed18
+    hipModule_t asmModule[4] = {nullptr, nullptr, nullptr, nullptr}; hipFunction_t asmFn[4] = {nullptr, nullptr, nullptr, nullptr};      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract)
+    bool debugExactExtend = false;  // pt_debug_intersect always probes the exact kernels
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
     int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
+    int streamsOnDevice = 1;        // streams of the same multi-stream context on this context's GPU (pt_create_multi)
+    bool extendCacheSet = false;    // pt_set_option 6 was used: the tile size is the caller's
+    bool fastContract = false, streamFast = false;      // the relaxed numeric contract (pt_set_option 16) as set / as the running stream was started with
     int asmLoop = -1;               // hand-written kernel's main loop: -1 automatic, 0 phase-voting, 1 fused trip (pt_set_option 14)
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
     int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 0; int innerKeepEighths = 6;
@@ -1197,13 +1201,12 @@ static_assert(sizeof(EpAsmArgs) == 120, "EpAsmArgs layout is part of the assembl
 #include PT_EXTEND_INC              // the assembled code objects (build.py): pt_extend_hsaco_s16[], pt_extend_hsaco_p18[]
 
 int loadAsmKernel(pt_ctx* c) {
-    if (c->asmFn[0]) return 0;
-    hipModule_t m0 = nullptr, m1 = nullptr;
-    HIP_TRY(hipModuleLoadData(&m0, pt_extend_hsaco_s16));
-    HIP_TRY(hipModuleLoadData(&m1, pt_extend_hsaco_p18));
-    HIP_TRY(hipModuleGetFunction(&c->asmFn[0], m0, "pt_extend_asm"));
-    HIP_TRY(hipModuleGetFunction(&c->asmFn[1], m1, "pt_extend_asm"));
-    c->asmModule = m0; c->asmModule2 = m1;
+    if (c->asmFn[3]) return 0;
+    const void* images[4] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f};
+    for (int k = 0; k < 4; k++) {
+        HIP_TRY(hipModuleLoadData(&c->asmModule[k], images[k]));
+        HIP_TRY(hipModuleGetFunction(&c->asmFn[k], c->asmModule[k], "pt_extend_asm"));
+    }
     return 0;
 }
 
@@ -1211,11 +1214,19 @@ int loadAsmKernel(pt_ctx* c) {
 bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     if (!c->asmEligible || c->countStats || c->streamIn.params[9] != 1.0f || c->ellipMaps || c->extendTpb != 256) return false;
     const DevScene& sc = c->sc;
-    const size_t fixed = (size_t)sc.numObj * 1024 + 32 + (size_t)c->stackDepth * 512;
+    const size_t fixed = (size_t)sc.numObj * 1024 + 48 + (size_t)c->stackDepth * 512;      // root-box distances, root references + ray cursor, traversal stacks
     if (fixed + 2048 > 64 * 1024) return false;
-    size_t cb = std::min<size_t>((size_t)c->extendCacheBytes, 64 * 1024 - fixed);
+    // Blocks per CU and tile: alone on the GPU the kernel wants every wave slot (8 blocks of 256 threads, 8 KB tile).  When the context's streams
+    // share the GPU (pt_create_multi with a device listed more than once) 6 blocks with a 16 KB tile are worth more: the two slots per SIMD it
+    // leaves let the other stream's shading blocks run beside it instead of behind it (C3 +3.5 %, C4 +3 %, C5 +2.5 % over 8 blocks,
+    // profiles/r03_d_blocks_per_cu_and_tile.txt) — unless the whole scene fits the small tile anyway (C2).
+    const bool wholeSceneInSmallTile = (size_t)sc.nNodes * 80 + (size_t)sc.nTriRecs * 48 <= 8192;
+    const bool shareSlots = c->streamsOnDevice > 1 && !wholeSceneInSmallTile;
+    const int maxBlocks = c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : (shareSlots ? 6 : 8);
+    const size_t tileWanted = c->extendCacheSet ? (size_t)c->extendCacheBytes : (shareSlots ? 16384 : 8192);
+    size_t cb = std::min<size_t>(tileWanted, 64 * 1024 - fixed);
     {   // the node tile gives way to residency, as in launchExtendPersist
-        const int want = c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : 8;
+        const int want = maxBlocks;
         const size_t perBlock = (size_t)160 * 1024 / (size_t)want;
         if (fixed + cb + 16 > perBlock && perBlock > fixed + 16 + 2048) cb = std::min(cb, (perBlock - fixed - 16) & ~(size_t)15);
     }
@@ -1224,8 +1235,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     a.ldsTris = (a.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)a.ldsNodes * 80) / 48) : 0;
     size_t lds = (size_t)a.ldsNodes * 80 + (size_t)a.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
-    int perCU = std::max(1, std::min((int)(160 * 1024 / lds), 8));
-    if (c->extendMaxBlocksPerCU > 0) perCU = std::min(perCU, c->extendMaxBlocksPerCU);
+    int perCU = std::max(1, std::min((int)(160 * 1024 / lds), maxBlocks));
     int grid = c->numCUs * perCU;
     grid = std::max(1, std::min(grid, ((int)pr.launched + 255) / 256));
     if (loadAsmKernel(c)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
@@ -1249,7 +1259,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     }
     size_t asz = sizeof(a);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(c->asmFn[c->stackMode == 1 ? 1 : 0], (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(c->asmFn[(c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0)], (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
     if (e != hipSuccess) { c->asmError = std::string("hipModuleLaunchKernel(pt_extend_asm): ") + hipGetErrorString(e); return false; }
     c->asmLaunches++;
     return true;
@@ -1336,6 +1346,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     // next stream (submitBatch finishes this one first), so the remaining iterations keep their kernel variants and bounds
     const float* P = c->streamIn.params;
     const bool direct = P[9] != 1.0f;
+    const bool fastNow = c->streamFast;                           // the contract the running stream was started with
     const Batch b = streamBatch(c);
     const int N = c->poolActive;
     size_t ldsBytes = (size_t)c->sc.ldsNodes * 64 + (size_t)c->sc.ldsTris * 48 + (size_t)c->stackDepth * BLOCK * 4;
@@ -1381,7 +1392,9 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
 #define SHADE_ARGS dim3(std::max(1, (int)((pr.launched + SHADE_BLOCK - 1) / SHADE_BLOCK))), dim3(SHADE_BLOCK), 0, s, c->sc, b, c->dFc, pr.st, c->dQueue[pr.iter & 1], c->dQueue[(pr.iter + 1) & 1], pr.iter, (int)pr.launched, c->dCtl
             // kernel variant: transmissive materials present / statistics on / RAYTRACING == 0 / texture-mapped materials present
 #define SHADE_V(T, S, D, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
-#define SHADE_S(T, D, X) do { if (c->countStats) SHADE_V(T, true, D, X); else SHADE_V(T, false, D, X); } while (0)
+#define SHADE_F(T, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, false, false, X, true>), SHADE_ARGS))
+            // (the relaxed numeric contract, pt_set_option 16: path tracing without statistics only; everything else keeps the exact kernels)
+#define SHADE_S(T, D, X) do { if (c->countStats) SHADE_V(T, true, D, X); else if (fastNow && !(D)) SHADE_F(T, X); else SHADE_V(T, false, D, X); } while (0)
 #define SHADE_X(T, D) do { if (c->anyMaps) SHADE_S(T, D, true); else SHADE_S(T, D, false); } while (0)
             if (direct) SHADE_X(false, true);
             else if (c->trans) SHADE_X(true, false);
@@ -1467,7 +1480,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         const size_t rowBytes = (size_t)c->nSlotsImg * 16;
         wantRing = std::max(pt_ctx::IMAGES * nFrames, (int)std::min<size_t>(64, std::max<size_t>(1, ((size_t)8 << 30) / rowBytes)));
     }
-    bool join = !c->pending.empty() && !c->sceneDirty && std::memcmp(&fin, &c->streamIn, sizeof(FrameIn)) == 0 && c->ringFrames >= wantRing &&
+    bool join = !c->pending.empty() && !c->sceneDirty && std::memcmp(&fin, &c->streamIn, sizeof(FrameIn)) == 0 && c->ringFrames >= wantRing && c->streamFast == c->fastContract &&
                 (uint64_t)c->streamJobs + nJobs64 < (1ull << 31);
     if (!join && (rc = flushStream(c))) return rc;
     if (!join) {                                                  // ---- a new stream
@@ -1495,7 +1508,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
             HIP_TRY(hipHostMalloc((void**)&c->hSeeds, (size_t)wantRing * 4, hipHostMallocDefault));
             c->ringFrames = wantRing;
         }
-        c->streamIn = fin; *c->hFrameIn = fin;
+        c->streamIn = fin; *c->hFrameIn = fin; c->streamFast = c->fastContract;
         HIP_TRY(hipMemcpyAsync(c->dFrameIn, c->hFrameIn, sizeof(FrameIn), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, s, c->sc, c->dFrameIn, c->dFc, c->dEllip);
         hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl);
@@ -1530,8 +1543,11 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     hipLaunchKernelGGL(k_submit, dim3(1), dim3(1), 0, s, c->dCtl, (unsigned)nJobs64, join ? (grown ? 2 : 0) : 1, (unsigned)c->poolActive);
     const Batch b = streamBatch(c);
     const int N = c->poolActive;
-    if (c->trans) TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<true>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
-    else TIMED_LAUNCH(2, hipLaunchKernelGGL(k_revive<false>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl));
+#define REVIVE(T, F) TIMED_LAUNCH(2, hipLaunchKernelGGL((k_revive<T, F>), dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl))
+    const bool fastRevive = c->streamFast && !direct && !c->countStats;
+    if (c->trans) { if (fastRevive) REVIVE(true, true); else REVIVE(true, false); }
+    else { if (fastRevive) REVIVE(false, true); else REVIVE(false, false); }
+#undef REVIVE
     c->streamFrames += (unsigned)nFrames; c->streamJobs += (unsigned)nJobs64;
     c->lastSubmitJobs = nJobs64; c->jobsThisImage += nJobs64;
     pt_ctx::Entry e; e.jobEnd = c->streamJobs; e.f0 = f0; e.nFrames = nFrames; e.firstFrame = firstFrame; e.image = c->curImage;
@@ -1670,6 +1686,7 @@ int pt_create_multi_part(pt_ctx** out, const int* devices, int n_devices, int wi
     int rc = 0; std::string err;
     for (int i = 0; i < n_devices; i++) { int r = M->workers[i]->wait(); if (r && !rc) { rc = r; err = "device " + std::to_string(devices[i]) + ": " + M->workers[i]->err; } }
     if (rc) { M->kids.erase(std::remove(M->kids.begin(), M->kids.end(), nullptr), M->kids.end()); multiFree(g); delete g; return fail(rc, err); }
+    for (const auto& r : runs) for (int j = 0; j < r.count; j++) M->kids[r.first + j]->streamsOnDevice = virtualDevices > 1 ? n_devices : r.count;
     *out = g;
     // Streams that share a GPU overlap only on different hardware queues.  The HIP runtime deals streams to queues round-robin when
     // GPU_MAX_HW_QUEUES is set — a variable it reads ONCE, when the process initialises HIP, so it is the host's to set;
@@ -1692,8 +1709,7 @@ int pt_destroy(pt_ctx* c) {
     hipSetDevice(c->device);
     flushStream(c);
     hipStreamSynchronize(c->stream);
-    if (c->asmModule) hipModuleUnload(c->asmModule);
-    if (c->asmModule2) hipModuleUnload(c->asmModule2);
+    for (hipModule_t m : c->asmModule) if (m) hipModuleUnload(m);
     void* ptrs[] = {c->dNodes80, c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1893,6 +1909,58 @@ int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out
     return PT_OK;
 }
 
+namespace {
+// minimal PNG writer: IHDR + one IDAT of stored (uncompressed) deflate blocks + IEND
+uint32_t crc32_(const uint8_t* p, size_t n, uint32_t c) {
+    static uint32_t T[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t x = i; for (int k = 0; k < 8; k++) x = (x & 1) ? 0xedb88320u ^ (x >> 1) : x >> 1; T[i] = x; } init = true; }
+    c = ~c;
+    for (size_t i = 0; i < n; i++) c = T[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    return ~c;
+}
+void pngChunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+    auto be32 = [&](uint32_t v) { for (int k = 3; k >= 0; k--) out.push_back((uint8_t)(v >> (8 * k))); };
+    be32((uint32_t)data.size());
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4); out.insert(out.end(), data.begin(), data.end());
+    be32(crc32_(out.data() + at, out.size() - at, 0));
+}
+std::vector<uint8_t> encodePng(const uint8_t* rgb, int W, int H) {
+    std::vector<uint8_t> raw; raw.reserve((size_t)H * (3 * (size_t)W + 1));
+    for (int y = 0; y < H; y++) { raw.push_back(0); raw.insert(raw.end(), rgb + (size_t)y * W * 3, rgb + (size_t)(y + 1) * W * 3); }      // filter type 0 per scanline
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < raw.size(); i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xff)); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)(~n & 0xff)); z.push_back((uint8_t)((~n >> 8) & 0xff));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    for (int k = 3; k >= 0; k--) z.push_back((uint8_t)(((b << 16) | a) >> (8 * k)));
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    std::vector<uint8_t> ihdr;
+    for (uint32_t v : {(uint32_t)W, (uint32_t)H}) for (int k = 3; k >= 0; k--) ihdr.push_back((uint8_t)(v >> (8 * k)));
+    for (uint8_t v : {8, 2, 0, 0, 0}) ihdr.push_back(v);          // 8 bits, colour type 2 (RGB), deflate, adaptive filtering, no interlace
+    pngChunk(out, "IHDR", ihdr); pngChunk(out, "IDAT", z); pngChunk(out, "IEND", {});
+    return out;
+}
+}  // namespace
+
+int pt_save_png(pt_ctx* c, int frame_count, int java_bytes, const char* path) {
+    if (!c || !path) return fail(PT_ERR_ARG, "pt_save_png: null argument");
+    std::vector<uint8_t> rgb((size_t)c->W * c->H * 3);
+    int rc = pt_read_display(c, frame_count, java_bytes, rgb.data());
+    if (rc) return rc;
+    const std::vector<uint8_t> png = encodePng(rgb.data(), c->W, c->H);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(PT_ERR_ARG, std::string("pt_save_png: cannot open ") + path);
+    const bool ok = std::fwrite(png.data(), 1, png.size(), f) == png.size();
+    if (std::fclose(f) != 0 || !ok) return fail(PT_ERR_ARG, std::string("pt_save_png: short write to ") + path);
+    return PT_OK;
+}
+
 /* One image of a multi-GPU context: finish image `age` on every device, ONE RCCL gather of the packed accumulators on device[0],
  * un-tile there (stream-ordered on device[0]'s stream, not synchronised).  A one-device context returns its own image. */
 int pt_gather_image(pt_ctx* c, int age, void** full_dev) {
@@ -1968,6 +2036,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
         case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; return PT_OK;
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
+        case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)
         case 12: {                                                // query (debug): 0 = the current scene runs on the hand-written intersect kernel, else PT_ERR_UNSUPPORTED + why not
@@ -1975,7 +2044,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
             return c->asmEligible ? PT_OK : fail(PT_ERR_UNSUPPORTED, "compiled intersect kernel: " + c->asmWhyNot);
         }
         case 5: if (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "extend block size must be 64, 128, 256, 512 or 1024"); c->extendTpb = (int)value; return PT_OK;
-        case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->sceneDirty = true; return PT_OK;
+        case 6: if (value < 0 || value > 150 * 1024) return fail(PT_ERR_ARG, "extend LDS cache bytes out of range"); c->extendCacheBytes = (int)value; c->extendCacheSet = true; c->sceneDirty = true; return PT_OK;
         case 7: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "refill threshold must be in [1,64]"); c->refillMin = (int)value; return PT_OK;
         case 8: if (value < 0 || value > 32) return fail(PT_ERR_ARG, "blocks per CU must be in [0,32]"); c->extendMaxBlocksPerCU = (int)value; return PT_OK;
         case 9: if (value < 0 || value > 8) return fail(PT_ERR_ARG, "inner-phase persistence must be in [0,8] eighths"); c->innerKeepEighths = (int)value; return PT_OK;
@@ -2124,7 +2193,9 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     } else {                                                      // the production kernels (persistent blocks; hand-written or compiled), as pump() launches them
         std::memcpy(c->streamIn.params, fin.params, 48); c->streamIn.params[9] = 1.0f;      // no thickness probes in this pool
         PoolRun pr; pr.stream = c->stream; pr.st = st; pr.launched = (unsigned)np; pr.iter = 0;
+        c->debugExactExtend = true;
         launchExtendPersist(c, pr);
+        c->debugExactExtend = false;
         std::memset(&c->streamIn, 0xff, sizeof(FrameIn));
     }
     HIP_TRY(hipGetLastError());

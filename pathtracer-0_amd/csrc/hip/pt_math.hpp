@@ -169,6 +169,35 @@ PM_DEV vec3 mix(vec3 x, vec3 y, float a) { return madd(y, a, x * (1.0f - a)); }
 // exp() applied component-wise
 PM_DEV vec3 exp3(vec3 a) { return {exp_(a.x), exp_(a.y), exp_(a.z)}; }
 
+// ---- the opt-in relaxed contract (pt_set_option: numeric_contract = 1, bench.py --contract fast) ------------------------------
+// The exact contract above prices Box-Muller at ~90 instructions per Gaussian and every divide / sqrt / normalize at 11-13.  The relaxed
+// one keeps the RNG, the draw counts and every branch of the shader as written and only evaluates the continuous functions with the
+// hardware's units (v_rcp_f32, v_rsq_f32, v_sqrt_f32, v_log_f32, v_cos_f32: 1 ulp; v_cos ~1e-6 absolute).  Results are no longer
+// bit-identical to the oracle; the bar is north_star's per-pixel RMSE <= 1e-3, asserted by tests/test_gpu_parity.py::test_fast_contract_*.
+// Not part of oracle/glsl_math.h: the oracle only ever implements the exact contract.
+template <bool FAST> PM_DEV float rcpT(float x) { if (FAST) return __builtin_amdgcn_rcpf(x); return 1.0f / x; }
+template <bool FAST> PM_DEV float divT(float a, float b) { if (FAST) return a * __builtin_amdgcn_rcpf(b); return a / b; }
+template <bool FAST> PM_DEV float sqrtT(float x) { if (FAST) return __builtin_amdgcn_sqrtf(x); return __builtin_sqrtf(x); }
+template <bool FAST> PM_DEV vec3 normalizeT(vec3 a) { if (FAST) return a * __builtin_amdgcn_rsqf(dot(a, a)); return normalize(a); }
+template <bool FAST> PM_DEV float lengthT(vec3 a) { return sqrtT<FAST>(dot(a, a)); }
+// rho * cos(theta) of randValNormalDist (frag.glsl:696-701) from the two uniform draws
+template <bool FAST> PM_DEV float boxMullerT(float u1, float u2) {
+    if (FAST) {
+        const float rho = __builtin_amdgcn_sqrtf(-2.0f * (__builtin_amdgcn_logf(u2) * 0.69314718056f));      // v_log_f32 is log2
+        return rho * __builtin_amdgcn_cosf(u1 * (2.0f * 3.1415926f * 0.15915494309f));                      // v_cos_f32 takes revolutions
+    }
+    const float theta = 2.0f * 3.1415926f * u1;
+    const float rho = __builtin_sqrtf(-2.0f * log_(u2));
+    return rho * cos_(theta);
+}
+template <bool FAST> PM_DEV vec3 refractT(vec3 I, vec3 N, float eta) {
+    float d = dot(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return v3(0.0f);
+    float s = fma_(eta, d, sqrtT<FAST>(k));
+    return madd(N, -s, I * eta);
+}
+
 // min/max as used by rayBox (frag.glsl:412-415).  GLSL leaves NaN behaviour undefined; the
 // contract is IEEE minNum/maxNum (a NaN operand is ignored), which is what GPU min/max
 // instructions implement.  Only comparisons consume the results, so the sign of zero is moot.

@@ -52,6 +52,8 @@ public final class PtNative {
     public static native void readFrame(long ctx, Buffer rgbaOut);
     /** functions.screenshot's pixels (dispatch.java:804-833): width*height*3 bytes, top row first; javaBytes = keep its signed-byte packing */
     public static native void readDisplay(long ctx, int frameCount, boolean javaBytes, Buffer rgbOut);
+    /** what functions.screenshot writes (dispatch.java:804-851): those pixels as an 8-bit RGB PNG at `path` (pt_save_png) */
+    public static native void savePng(long ctx, int frameCount, boolean javaBytes, String path);
     /** PT_CNT_* statistics since resetCounters: segments, nodes, triangle tests, hit updates, samples, box tests, iterations, launches */
     public static native long[] getCounters(long ctx);
     public static native void resetCounters(long ctx);

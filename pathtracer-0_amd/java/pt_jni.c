@@ -114,6 +114,13 @@ JNIEXPORT void JNICALL Java_Main_PtNative_readDisplay(JNIEnv* env, jclass c, jlo
     if (!p) return;
     CHECK(pt_read_display(CTX(h), frameCount, javaBytes ? 1 : 0, (uint8_t*)p), "pt_read_display");
 }
+JNIEXPORT void JNICALL Java_Main_PtNative_savePng(JNIEnv* env, jclass c, jlong h, jint frameCount, jboolean javaBytes, jstring path) {
+    const char* p = path ? (*env)->GetStringUTFChars(env, path, NULL) : NULL;
+    if (!p) { (*env)->ThrowNew(env, (*env)->FindClass(env, "java/lang/IllegalArgumentException"), "savePng needs a path"); return; }
+    int rc = pt_save_png(CTX(h), frameCount, javaBytes ? 1 : 0, p);
+    (*env)->ReleaseStringUTFChars(env, path, p);
+    if (rc != PT_OK) throw_rt(env, "pt_save_png");
+}
 JNIEXPORT void JNICALL Java_Main_PtNative_synchronize(JNIEnv* env, jclass c, jlong h) { CHECK(pt_synchronize(CTX(h)), "pt_synchronize"); }
 JNIEXPORT void JNICALL Java_Main_PtNative_readFrame(JNIEnv* env, jclass c, jlong h, jobject out) {
     void* p = direct(env, out, "readFrame");

@@ -19,7 +19,7 @@ COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "i
 KERNELS = {"extend": 0, "shade": 1, "generate": 2, "accumulate": 3}
 OPTIONS = {"path_slots": 0, "count_stats": 1, "lds_budget": 2, "none_min": 3, "extend_mode": 4, "extend_tpb": 5, "extend_cache_bytes": 6,
            "refill_min": 7, "extend_blocks_per_cu": 8, "inner_keep_eighths": 9, "bfs_nodes": 10, "stack_mode": 11,
-           "query_asm_eligible": 12, "query_asm_launches_above": 13, "asm_loop": 14}
+           "query_asm_eligible": 12, "query_asm_launches_above": 13, "asm_loop": 14, "numeric_contract": 16}
 
 
 def hip_runtimes_mapped():
@@ -97,6 +97,7 @@ def lib():
         L.pt_stream_wait.argtypes = [vp]
         L.pt_read_frame.argtypes = [vp, vp]
         L.pt_read_display.argtypes = [vp, ci, ci, vp]
+        L.pt_save_png.argtypes = [vp, ci, ci, C.c_char_p]
         L.pt_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
         L.pt_shard_slots.argtypes = [ci, ci, ci, C.POINTER(sz)]
         L.pt_shard_map.argtypes = [ci, ci, ci, ci, vp, sz]
@@ -247,8 +248,8 @@ class Renderer:
         return out
 
     def screenshot(self, path, frame_count, java_bytes=True):
-        from PIL import Image
-        Image.fromarray(self.read_display(frame_count, java_bytes)).save(path)
+        """functions.screenshot(fileName) (dispatch.java:804-851): the display image as a PNG file, written by the library (pt_save_png)"""
+        _check(self._L.pt_save_png(self._h, int(frame_count), 1 if java_bytes else 0, str(path).encode()))
 
     def frame_device(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -21,11 +21,11 @@ import csv, glob, json
 for f in glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True):
     print("name,calls,total_ms,avg_us,percent,min_us,max_us")
     for row in csv.DictReader(open(f)):
-        n=row["Name"]; i=n.find("k_"); n=n[i:i+40] if i>=0 else n[:40]
+        n=row["Name"]; i=n.find("k_") if "pt_extend_asm" not in n else n.find("pt_extend_asm"); n=n[i:i+40] if i>=0 else n[:40]
         print(f"{n},{row['Calls']},{float(row['TotalDurationNs'])/1e6:.3f},{float(row['AverageNs'])/1e3:.2f},{float(row['Percentage']):.3f},{float(row['MinNs'])/1e3:.2f},{float(row['MaxNs'])/1e3:.2f}")
 for l in open("$O/bench_trace.json"):
     if l.startswith("{"):
-        d=json.loads(l); print("bench line of the traced run:", json.dumps({k:d[k] for k in ("value","ms_per_step","steps")}), json.dumps({k:d["roofline"][k] for k in ("avg_launch_ms","launches","frac")}), "shade avg", d["roofline"]["shade"]["avg_launch_ms"])
+        d=json.loads(l); print("bench line of the traced run:", json.dumps({k:d[k] for k in ("value","ms_per_step","steps")}), json.dumps({k:d["roofline"]["in_run"][k] for k in ("avg_launch_ms","launches","frac")}), "shade avg", d["roofline"]["shade"]["in_run"]["avg_launch_ms"])
 PY
 rm -rf $O/trace
 # 4. tile-shard rehearsals (one shard of N alone on this GPU) and the multi-GPU context with two shards on this GPU

@@ -44,7 +44,7 @@ def main(d, cfg, fps):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for f in glob.glob(f"{d}/set*/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            m = re.search(r"(k_[a-z_]+)", row["Kernel_Name"])
+            m = re.search(r"(k_[a-z_]+|pt_extend_asm)", row["Kernel_Name"])
             k = m.group(1) if m else "other"
             a = agg[k][row["Counter_Name"]]
             a[0] += 1
@@ -59,19 +59,19 @@ def main(d, cfg, fps):
         sres = plain["config"]["spp_per_step"] // fps
         seg = W * H * sres * fps * 2 * S
         out.update({"segments_per_sample": S, "segments_in_a_pass": seg, "plain_run": {"value": plain["value"], "ms_per_step": plain["ms_per_step"],
-                    "extend_avg_launch_ms": rf.get("avg_launch_ms"), "shade_avg_launch_ms": (rf.get("shade") or {}).get("avg_launch_ms", rf.get("shade_avg_launch_ms")),
-                    "extend_launches": rf.get("launches"),
+                    "extend_avg_launch_ms": (rf.get("in_run") or rf).get("avg_launch_ms"), "shade_avg_launch_ms": ((rf.get("shade") or {}).get("in_run") or rf.get("shade") or {}).get("avg_launch_ms"),
+                    "extend_launches": (rf.get("in_run") or rf).get("launches"),
                     "per_segment": rf.get("per_segment")}})
     else:
         seg = None
     for k, v in sorted(agg.items()):
-        if k not in ("k_extend_persist", "k_extend", "k_shade", "k_accumulate", "k_revive"):
+        if k not in ("pt_extend_asm", "k_extend_persist", "k_extend", "k_shade", "k_accumulate", "k_revive"):
             continue
         tot = {c: x[1] for c, x in v.items()}
         n = max(x[0] for x in v.values())
         o = {"launches_per_pass": n, "totals": {c: round(x) for c, x in sorted(tot.items())}}
         g = tot.get
-        if seg and k in ("k_extend_persist", "k_extend", "k_shade"):
+        if seg and k in ("pt_extend_asm", "k_extend_persist", "k_extend", "k_shade"):
             if g("SQ_INSTS_VALU"):
                 o["valu_per_segment"] = round(g("SQ_INSTS_VALU") / seg, 3)
                 o["salu_per_segment"] = round(g("SQ_INSTS_SALU", 0) / seg, 3)
@@ -97,8 +97,9 @@ def main(d, cfg, fps):
                             ("valu_active_share", "SQ_ACTIVE_INST_VALU"), ("scalar_active_share", "SQ_ACTIVE_INST_SCA")):
                 if c in t:
                     o[name] = round(t[c] / wc, 4)
-    if plain and "k_extend_persist" in out["kernels"]:
-        o = out["kernels"]["k_extend_persist"]
+    ext = "pt_extend_asm" if "pt_extend_asm" in out["kernels"] else "k_extend_persist"      # the hand-written intersect kernel, or the compiled one
+    if plain and ext in out["kernels"]:
+        o = out["kernels"][ext]
         pr = out["plain_run"]
         if pr["extend_avg_launch_ms"] and pr["extend_launches"] and "valu_per_segment" in o:
             seg_rate = (seg / 2.0) / (pr["extend_avg_launch_ms"] * 1e-3 * pr["extend_launches"])      # segments/s while the kernel runs (timed step of the plain run)

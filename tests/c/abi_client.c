@@ -42,6 +42,7 @@ static int (*pt_image_device_)(pt_ctx*, int, void**, size_t*);
 static int (*pt_gather_image_)(pt_ctx*, int, void**);
 static int (*pt_synchronize_)(pt_ctx*);
 static int (*pt_read_display_)(pt_ctx*, int, int, uint8_t*);
+static int (*pt_save_png_)(pt_ctx*, int, int, const char*);
 static int (*pt_frame_device_)(pt_ctx*, void**, size_t*);
 static int (*pt_shard_slots_)(int, int, int, size_t*);
 static int (*pt_shard_map_)(int, int, int, int, int32_t*, size_t);
@@ -89,7 +90,7 @@ int main(int argc, char** argv) {
     SYM(hip, pt_create) SYM(hip, pt_destroy) SYM(hip, pt_last_error) SYM(hip, pt_set_buffer) SYM(hip, pt_set_texture) SYM(hip, pt_reset_frame)
     SYM(hip, pt_render) SYM(hip, pt_read_frame)
     SYM(hip, pt_create_multi) SYM(hip, pt_create_multi_part) SYM(hip, pt_stream_wait) SYM(hip, pt_render_batch) SYM(hip, pt_render_batch_async) SYM(hip, pt_next_image) SYM(hip, pt_finish_image) SYM(hip, pt_image_device)
-    SYM(hip, pt_gather_image) SYM(hip, pt_synchronize) SYM(hip, pt_read_display) SYM(hip, pt_frame_device) SYM(hip, pt_shard_slots) SYM(hip, pt_shard_map)
+    SYM(hip, pt_gather_image) SYM(hip, pt_synchronize) SYM(hip, pt_read_display) SYM(hip, pt_save_png) SYM(hip, pt_frame_device) SYM(hip, pt_shard_slots) SYM(hip, pt_shard_map)
     SYM(hip, pt_unshard) SYM(hip, pt_set_stream) SYM(hip, pt_build_bvh) SYM(hip, pt_get_counters) SYM(hip, pt_reset_counters)
     void* rt = dlopen("libamdhip64.so", RTLD_NOW);
     if (!rt) { fprintf(stderr, "dlopen libamdhip64.so: %s\n", dlerror()); return 2; }
@@ -144,6 +145,14 @@ int main(int argc, char** argv) {
     REQUIRE(pt_read_display_(ctx, frames, 1, rgb) == 0, "pt_read_display");
     unsigned long nz = 0; for (size_t k = 0; k < (size_t)W * H * 3; k++) nz += rgb[k] != 0;
     REQUIRE(nz > (unsigned long)W * H, "pt_read_display shows a picture");
+    {   /* the screenshot file: signature, IHDR with the image size, an IDAT and an IEND */
+        char path[256]; snprintf(path, sizeof path, "/tmp/abi_client_%dx%d_%d.png", W, H, frames);
+        REQUIRE(pt_save_png_(ctx, frames, 1, path) == 0, "pt_save_png");
+        FILE* pf = fopen(path, "rb"); REQUIRE(pf != NULL, "pt_save_png wrote a file");
+        unsigned char hd[24]; size_t got = fread(hd, 1, sizeof hd, pf); fclose(pf); remove(path);
+        REQUIRE(got == sizeof hd && memcmp(hd, "\x89PNG\r\n\x1a\n", 8) == 0 && memcmp(hd + 12, "IHDR", 4) == 0, "PNG signature and IHDR");
+        REQUIRE(((hd[16] << 24) | (hd[17] << 16) | (hd[18] << 8) | hd[19]) == W && ((hd[20] << 24) | (hd[21] << 16) | (hd[22] << 8) | hd[23]) == H, "PNG size");
+    }
     REQUIRE(pt_set_stream_(ctx, NULL) == 0, "pt_set_stream(NULL) = the context's own stream");
     /* tile shards: maps partition the image; two shard contexts + pt_unshard rebuild the frame */
     size_t sslots = 0;
