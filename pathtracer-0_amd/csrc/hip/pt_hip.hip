@@ -847,6 +847,7 @@ struct pt_ctx {
     int streamsOnDevice = 1;        // streams of the same multi-stream context on this context's GPU (pt_create_multi)
     bool extendCacheSet = false;    // pt_set_option 6 was used: the tile size is the caller's
     bool fastContract = false, streamFast = false;      // the relaxed numeric contract (pt_set_option 16) as set / as the running stream was started with
+    int leafMin = 1;                // fused trip: lanes on leaves that make the triangle step worth running beside the node step (pt_set_option 15)
     int asmLoop = -1;               // hand-written kernel's main loop: -1 automatic, 0 phase-voting, 1 fused trip (pt_set_option 14)
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
     int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 0; int innerKeepEighths = 6;
@@ -1246,10 +1247,11 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)
     const bool allInLds = a.ldsNodes == sc.nNodes && a.ldsTris == sc.nTriRecs;
     a.mode = c->asmLoop >= 0 ? (unsigned)c->asmLoop : (allInLds ? 0u : 1u);
+    if (a.mode) a.keepEighths = c->leafMin;      // the fused loop reads this argument as its leaf-lane threshold
     a.nWaves = (unsigned)grid * 4u;
     if (getenv("PT_ASM_DEBUG")) {
-        if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 32) != hipSuccess) return false; }
-        hipMemsetAsync(c->dAsmDbg, 0xff, 8192 * 32, pr.stream);
+        if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 64) != hipSuccess) return false; }
+        hipMemsetAsync(c->dAsmDbg, 0xff, 8192 * 64, pr.stream);
         a.dbg = c->dAsmDbg;
     }
     {   // x / nWaves == mulhi(x, divM) >> divS for x < 2^31 (nWaves >= 4)
@@ -2038,6 +2040,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
+        case 15: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "leaf-lane threshold must be in [1,64]"); c->leafMin = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)
         case 12: {                                                // query (debug): 0 = the current scene runs on the hand-written intersect kernel, else PT_ERR_UNSUPPORTED + why not
             if (c->sceneDirty) { int rc = buildScene(c); if (rc) return rc; }
@@ -2099,8 +2102,8 @@ int pt_debug_phase_stats(pt_ctx* c, uint64_t* out, int n) {
     Control h;
     HIP_TRY(hipMemcpy(&h, c->dCtl, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < n && k < 16; k++) out[k] = h.dbg[k];
-    if (c->dAsmDbg && n >= 16 + 8192 * 4) {                       // developer builds of the hand-written kernel (-DPT_ASM_DEBUG / -DPT_ASM_PROF): 8 words per wave of the last launch
-        HIP_TRY(hipMemcpy(out + 16, c->dAsmDbg, 8192 * 32, hipMemcpyDeviceToHost));
+    if (c->dAsmDbg && n >= 16 + 8192 * 8) {                       // developer builds of the hand-written kernel (-DPT_ASM_DEBUG / -DPT_ASM_PROF): 16 words per block of the last launch
+        HIP_TRY(hipMemcpy(out + 16, c->dAsmDbg, 8192 * 64, hipMemcpyDeviceToHost));
         return PT_OK;
     }
 #if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
@@ -2204,9 +2207,9 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     std::vector<float> h(np * 4);
     HIP_TRY(hipMemcpy(h.data(), st.H, np * 16, hipMemcpyDeviceToHost));
     if (c->dAsmDbg && getenv("PT_ASM_DEBUG")) {
-        std::vector<unsigned> dbg(8192 * 8);
+        std::vector<unsigned> dbg(8192 * 16);
         HIP_TRY(hipMemcpy(dbg.data(), c->dAsmDbg, dbg.size() * 4, hipMemcpyDeviceToHost));
-        for (int w = 0; w < 24; w++) { fprintf(stderr, "asm wave %d:", w); for (int k = 0; k < 8; k++) fprintf(stderr, " %u", dbg[8 * w + k]); fprintf(stderr, "\n"); }
+        for (int w = 0; w < 24; w++) { fprintf(stderr, "asm wave %d:", w); for (int k = 0; k < 9; k++) fprintf(stderr, " %u", dbg[16 * w + k]); fprintf(stderr, "\n"); }
     }
     std::memcpy(out, h.data(), n * 16);
     return PT_OK;

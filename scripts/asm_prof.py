@@ -24,14 +24,19 @@ for kv in sys.argv[3:]:
     k, v = kv.split("="); r.set_option(k, int(v)); print("option", k, v)
 # stop in the steady state: the last launch before the poll is a full one
 r.render_batch_async(1, [scenes.frame_seed(f) for f in range(1, frames + 1)])
-out = np.zeros(16 + 8192 * 4, np.uint64)
+out = np.zeros(16 + 8192 * 8, np.uint64)
 L = renderer.lib(); L.pt_debug_phase_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 L.pt_debug_phase_stats(r._h, out.ctypes.data, out.size)
-w = out[16:].view(np.uint32).reshape(8192, 8)
-w = w[w[:, 0] != 0xffffffff]
-names = ("votes+rest", "node fetch wait", "node step", "tri fetch wait", "tri step", "next BVH/retire", "refill")
-tot = w[:, :7].astype(np.float64).sum()
-print(name, "waves", len(w), "cycles per wave %.0f" % (tot / max(len(w), 1)), "node steps per wave %.1f" % w[:, 7].mean())
+w = out[16:].view(np.uint32).reshape(8192, 16)      # one record per BLOCK (the last of its waves to finish wrote it)
+w = w[w[:, 0] != 0xffffffff].astype(np.float64)
+fused = not any(a == "asm_loop=0" for a in sys.argv[3:]) and name != "C2"
+names = (("loop overhead", "wait for the records", "node step", "triangle step", "wait for the pops", "requesting the next records", "next BVH / retire") if fused else
+         ("votes+rest", "node fetch wait", "node step", "tri fetch wait", "tri step", "next BVH/retire", "-"))
+life = w[:, 8].sum()
+print(name, "fused trip" if fused else "phase-voting loop", "- waves sampled", len(w), " cycles per wave %.0f" % (life / max(len(w), 1)), " trips per wave %.1f" % w[:, 7].mean())
+acc = 0.0
 for k, nm in enumerate(names):
-    print(f"  {nm:18s} {100 * w[:, k].astype(np.float64).sum() / tot:5.1f} %   per node step: {w[:, k].astype(np.float64).sum() / max(w[:, 7].sum(), 1):7.1f} cycles")
+    t = w[:, k].sum(); acc += t
+    print(f"  {nm:28s} {100 * t / life:5.1f} %   per trip: {t / max(w[:, 7].sum(), 1):7.1f} cycles")
+print(f"  {'refills (the rest)':28s} {100 * (life - acc) / life:5.1f} %")
 r.synchronize(); r.close()
