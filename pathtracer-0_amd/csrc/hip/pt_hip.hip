@@ -847,7 +847,6 @@ struct pt_ctx {
     int streamsOnDevice = 1;        // streams of the same multi-stream context on this context's GPU (pt_create_multi)
     bool extendCacheSet = false;    // pt_set_option 6 was used: the tile size is the caller's
     bool fastContract = false, streamFast = false;      // the relaxed numeric contract (pt_set_option 16) as set / as the running stream was started with
-    int leafMin = 1;                // fused trip: lanes on leaves that make the triangle step worth running beside the node step (pt_set_option 15)
     int asmLoop = -1;               // hand-written kernel's main loop: -1 automatic, 0 phase-voting, 1 fused trip (pt_set_option 14)
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
     int pLdsNodes = 0, pLdsTris = 0; int extendMaxBlocksPerCU = 0; int innerKeepEighths = 6;
@@ -1247,7 +1246,6 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)
     const bool allInLds = a.ldsNodes == sc.nNodes && a.ldsTris == sc.nTriRecs;
     a.mode = c->asmLoop >= 0 ? (unsigned)c->asmLoop : (allInLds ? 0u : 1u);
-    if (a.mode) a.keepEighths = c->leafMin;      // the fused loop reads this argument as its leaf-lane threshold
     a.nWaves = (unsigned)grid * 4u;
     if (getenv("PT_ASM_DEBUG")) {
         if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 64) != hipSuccess) return false; }
@@ -2040,7 +2038,6 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
-        case 15: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "leaf-lane threshold must be in [1,64]"); c->leafMin = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)
         case 12: {                                                // query (debug): 0 = the current scene runs on the hand-written intersect kernel, else PT_ERR_UNSUPPORTED + why not
             if (c->sceneDirty) { int rc = buildScene(c); if (rc) return rc; }
