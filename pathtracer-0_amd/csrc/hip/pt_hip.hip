@@ -28,6 +28,7 @@
 #include "pt_device.hpp"
 
 #include <algorithm>
+#include <cstddef>
 #include <deque>
 #include <cmath>
 #include <cstdio>
@@ -74,6 +75,8 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned long long waveStart[8192]; // ... and started
 #endif
 };
+// pt_extend_gfx950.s reads these two by their byte offsets
+static_assert(offsetof(Control, exhausted) == 4 && offsetof(Control, qCount) == 96, "Control layout is part of the hand-written kernel");
 __device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return ctl->exhausted[(iter + 3) & 3] != 0; }
 
 struct State {              // SoA path pool, float4 groups (see header comment)

@@ -343,6 +343,24 @@ def test_render_parity_small_pool_and_packed_tail(pt, oracle, renderer_mod, slot
     assert_same(got, ref, cnt, ocnt)
 
 
+@pytest.mark.parametrize("slots,W,H", [(1 << 16, 24, 16), (2048, 40, 30), (256, 24, 16)])
+def test_pool_far_larger_than_the_first_batch(pt, oracle, renderer_mod, slots, W, H):
+    """a pool of which only a block or two come alive with the first batch, and frames appended to the running stream: the few live slots (and the
+    revived ones) hand out every job"""
+    wl = pt.scenes.build("C3", W, H)
+    seeds = seeds_for(pt, 1, 6)
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("path_slots", slots)
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch_async(1, seeds[:1])
+    r.render_batch_async(2, seeds[1:4])         # appended to the running stream
+    r.render_batch_async(5, seeds[4:])
+    got = r.read_frame()
+    r.close()
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, 6, seeds, nthreads=8)
+    assert_same(got, ref)
+
+
 def test_batch_equals_frame_at_a_time_and_frame_counter(pt, oracle, renderer_mod):
     """K7: FRAME.rgb = sum of frames, a = N, frame 1 overwrites (frag.glsl:924-933)"""
     wl = pt.scenes.build("C2", 64, 36)
