@@ -12,7 +12,7 @@ extern "C" {
 
 /* Tuning knobs: 0 = path slots in flight (default 0 = automatic: one per job of a synchronous batch within [2^20, 2^22]; 5/8 of the
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
- * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8; 1 = at once),
+ * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8, 2 in the fused loop of the hand-written kernel; 1 = at once),
  * 4 = intersect kernel (0 simple, one block per 256 rays; 1 persistent blocks, compiled; 2 = default: the hand-written form of 1, csrc/hip/pt_extend_gfx950.s,
  *     for the launches it takes — no ellipsoids, at most 8 BVHs, no empty leaves, ordered boxes, RAYTRACING == 1, statistics off — and 1 for the others),
  * 5 = persistent block size (64/128/256/512/1024, default 256), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,

@@ -847,6 +847,7 @@ struct pt_ctx {
     bool debugExactExtend = false;  // pt_debug_intersect always probes the exact kernels
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
     int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
+    bool noneMinSet = false;        // pt_set_option 3 was used
     int streamsOnDevice = 1;        // streams of the same multi-stream context on this context's GPU (pt_create_multi)
     bool extendCacheSet = false;    // pt_set_option 6 was used: the tile size is the caller's
     bool fastContract = false, streamFast = false;      // the relaxed numeric contract (pt_set_option 16) as set / as the running stream was started with
@@ -1249,6 +1250,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)
     const bool allInLds = a.ldsNodes == sc.nNodes && a.ldsTris == sc.nTriRecs;
     a.mode = c->asmLoop >= 0 ? (unsigned)c->asmLoop : (allInLds ? 0u : 1u);
+    if (a.mode && !c->noneMinSet) a.noneMin = 2;      // the fused loop serves lanes that wait for their next BVH sooner (C3 +1.8 %, C5 +1 %, C4 / one stream +-0: profiles/r03_c_main_loops.txt (8))
     a.nWaves = (unsigned)grid * 4u;
     if (getenv("PT_ASM_DEBUG")) {
         if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 64) != hipSuccess) return false; }
@@ -2037,7 +2039,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 0: if (value != 0 && (value < BLOCK || value > (1 << 26))) return fail(PT_ERR_ARG, "path slots must be 0 (automatic) or in [256, 2^26]"); c->poolSlots = (int)((value + BLOCK - 1) / BLOCK * BLOCK); return PT_OK;
         case 1: c->countStats = value != 0; return PT_OK;
         case 2: if (value < 0 || value > 160 * 1024) return fail(PT_ERR_ARG, "LDS budget out of range"); c->ldsBudget = (int)value; c->sceneDirty = true; return PT_OK;
-        case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; return PT_OK;
+        case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; c->noneMinSet = true; return PT_OK;
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
