@@ -22,6 +22,8 @@ extern "C" {
  * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 32-bit; -1 = automatic.
  * 14 = main loop of the hand-written intersect kernel: -1 automatic (default), 0 phase-voting like the compiled kernel, 1 fused trip (every lane on a node or
  *      a leaf advances each trip; a lane's record is requested the moment its entry is decided).
+ * 17 = block size of the hand-written intersect kernel: 0 automatic (default: 1024 threads — 2 blocks per CU over a 32 KB tile of the trees' top — when the
+ *      context has its GPU to itself and the launch gives every CU its two blocks, else 256 threads), 256, 1024.
  * 16 = numeric contract: 0 (default) exact — every float operation pinned, framebuffers bit-identical to the oracle; 1 relaxed — RNG, draw counts and
  *      branches as written, the continuous functions (Box-Muller's log / cos / sqrt, normalize, 1/d, 1/det, the BSDF weights' divides) on the
  *      hardware's v_log / v_cos / v_sqrt / v_rsq / v_rcp units: results within north_star's per-pixel RMSE <= 1e-3 of the oracle, not bit-identical.

@@ -843,7 +843,8 @@ struct pt_ctx {
     uint64_t asmLaunches = 0;
     bool asmEligible = false;       // this scene can run on the hand-written kernel (buildScene)
     std::string asmWhyNot;          // ... or why not (pt_debug: reported by option 12)
-    hipModule_t asmModule[4] = {nullptr, nullptr, nullptr, nullptr}; hipFunction_t asmFn[4] = {nullptr, nullptr, nullptr, nullptr};      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract)
+    hipModule_t asmModule[8] = {}; hipFunction_t asmFn[8] = {};      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract); [4..7] the same four with 1024-thread blocks
+    int asmTpb = 0;                 // threads per block of the hand-written kernel: 0 automatic (launchExtendAsm), 256, 1024
     bool debugExactExtend = false;  // pt_debug_intersect always probes the exact kernels
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
     int noneMin = 8;                // lanes waiting for their next object / retirement that make that phase worth a trip
@@ -1205,9 +1206,10 @@ static_assert(sizeof(EpAsmArgs) == 120, "EpAsmArgs layout is part of the assembl
 #include PT_EXTEND_INC              // the assembled code objects (build.py): pt_extend_hsaco_s16[], pt_extend_hsaco_p18[]
 
 int loadAsmKernel(pt_ctx* c) {
-    if (c->asmFn[3]) return 0;
-    const void* images[4] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f};
-    for (int k = 0; k < 4; k++) {
+    if (c->asmFn[7]) return 0;
+    const void* images[8] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f,
+                             pt_extend_hsaco_s16w, pt_extend_hsaco_p18w, pt_extend_hsaco_s16fw, pt_extend_hsaco_p18fw};
+    for (int k = 0; k < 8; k++) {
         HIP_TRY(hipModuleLoadData(&c->asmModule[k], images[k]));
         HIP_TRY(hipModuleGetFunction(&c->asmFn[k], c->asmModule[k], "pt_extend_asm"));
     }
@@ -1218,20 +1220,31 @@ int loadAsmKernel(pt_ctx* c) {
 bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     if (!c->asmEligible || c->countStats || c->streamIn.params[9] != 1.0f || c->ellipMaps || c->extendTpb != 256) return false;
     const DevScene& sc = c->sc;
-    const size_t fixed = (size_t)sc.numObj * 1024 + 48 + (size_t)c->stackDepth * 512;      // root-box distances, root references + ray cursor, traversal stacks
-    if (fixed + 2048 > 64 * 1024) return false;
+    // Block size.  What bounds this kernel is its CU's instruction issue and vector-memory pipe together (profiles/r03_h_*): node steps served from
+    // the LDS tile cost neither a tag lookup nor a round trip, and the tile is per BLOCK — the same bytes eight times over with 256-thread blocks.
+    // Alone on its GPU the kernel therefore runs 2 blocks of 1024 threads per CU over a 32 KB tile instead of 8 x 256 over 8 KB (C3 +6.6 %, C4 +10 %,
+    // C5 +7 %, C2 +-0).  When the context's streams share the GPU the small blocks win (their slots free one by one for the other stream's
+    // shading blocks: 1024-thread blocks -4...7 %), and so they do for a launch too small to give every CU its two large blocks.
+    const bool sharedGpu = c->streamsOnDevice > 1;
+    const size_t perLane = (size_t)sc.numObj * 4 + (size_t)c->stackDepth * 2;      // root-box distances + traversal stack of one lane
+    const bool largeFits = 2 * (perLane * 1024 + 48 + 16384) <= (size_t)160 * 1024;      // two large blocks per CU with at least a 16 KB tile each (deep trees: stacks)
+    const int TPB = c->asmTpb ? c->asmTpb : (!sharedGpu && largeFits && pr.launched >= (uint64_t)c->numCUs * 2048 ? 1024 : 256);
+    const int BPW = TPB / 256;                                  // how many 256-thread blocks one block stands for
+    const size_t fixed = (size_t)sc.numObj * 4 * TPB + 48 + (size_t)c->stackDepth * 2 * TPB;      // root-box distances, root references + ray cursor, traversal stacks
+    const size_t ldsPerCU = 160 * 1024;                        // gfx950; one block may take all of it
+    if (fixed + 2048 > ldsPerCU) return false;
     // Blocks per CU and tile: alone on the GPU the kernel wants every wave slot (8 blocks of 256 threads, 8 KB tile).  When the context's streams
     // share the GPU (pt_create_multi with a device listed more than once) 6 blocks with a 16 KB tile are worth more: the two slots per SIMD it
     // leaves let the other stream's shading blocks run beside it instead of behind it (C3 +3.5 %, C4 +3 %, C5 +2.5 % over 8 blocks,
     // profiles/r03_d_blocks_per_cu_and_tile.txt) — unless the whole scene fits the small tile anyway (C2).
     const bool wholeSceneInSmallTile = (size_t)sc.nNodes * 80 + (size_t)sc.nTriRecs * 48 <= 8192;
     const bool shareSlots = c->streamsOnDevice > 1 && !wholeSceneInSmallTile;
-    const int maxBlocks = c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : (shareSlots ? 6 : 8);
-    const size_t tileWanted = c->extendCacheSet ? (size_t)c->extendCacheBytes : (shareSlots ? 16384 : 8192);
-    size_t cb = std::min<size_t>(tileWanted, 64 * 1024 - fixed);
+    const int maxBlocks = std::max(1, (c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : (shareSlots ? 6 : 8)) / BPW);
+    const size_t tileWanted = c->extendCacheSet ? (size_t)c->extendCacheBytes : (shareSlots ? 16384 : 8192) * (size_t)BPW;
+    size_t cb = std::min<size_t>(tileWanted, ldsPerCU - fixed);
     {   // the node tile gives way to residency, as in launchExtendPersist
         const int want = maxBlocks;
-        const size_t perBlock = (size_t)160 * 1024 / (size_t)want;
+        const size_t perBlock = ldsPerCU / (size_t)want;
         if (fixed + cb + 16 > perBlock && perBlock > fixed + 16 + 2048) cb = std::min(cb, (perBlock - fixed - 16) & ~(size_t)15);
     }
     EpAsmArgs a{};
@@ -1239,9 +1252,9 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     a.ldsTris = (a.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)a.ldsNodes * 80) / 48) : 0;
     size_t lds = (size_t)a.ldsNodes * 80 + (size_t)a.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
-    int perCU = std::max(1, std::min((int)(160 * 1024 / lds), maxBlocks));
+    int perCU = std::max(1, std::min((int)(ldsPerCU / lds), maxBlocks));
     int grid = c->numCUs * perCU;
-    grid = std::max(1, std::min(grid, ((int)pr.launched + 255) / 256));
+    grid = std::max(1, std::min(grid, ((int)pr.launched + TPB - 1) / TPB));
     if (loadAsmKernel(c)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
@@ -1251,7 +1264,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     const bool allInLds = a.ldsNodes == sc.nNodes && a.ldsTris == sc.nTriRecs;
     a.mode = c->asmLoop >= 0 ? (unsigned)c->asmLoop : (allInLds ? 0u : 1u);
     if (a.mode && !c->noneMinSet) a.noneMin = 2;      // the fused loop serves lanes that wait for their next BVH sooner (C3 +1.8 %, C5 +1 %, C4 / one stream +-0: profiles/r03_c_main_loops.txt (8))
-    a.nWaves = (unsigned)grid * 4u;
+    a.nWaves = (unsigned)grid * (unsigned)(TPB / 64);
     if (getenv("PT_ASM_DEBUG")) {
         if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 64) != hipSuccess) return false; }
         hipMemsetAsync(c->dAsmDbg, 0xff, 8192 * 64, pr.stream);
@@ -1264,7 +1277,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     }
     size_t asz = sizeof(a);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(c->asmFn[(c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0)], (unsigned)grid, 1, 1, 256, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(c->asmFn[(c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0) + (TPB == 1024 ? 4 : 0)], (unsigned)grid, 1, 1, (unsigned)TPB, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
     if (e != hipSuccess) { c->asmError = std::string("hipModuleLaunchKernel(pt_extend_asm): ") + hipGetErrorString(e); return false; }
     c->asmLaunches++;
     return true;
@@ -2042,6 +2055,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; c->noneMinSet = true; return PT_OK;
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
+        case 17: if (value != 0 && value != 256 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)
         case 12: {                                                // query (debug): 0 = the current scene runs on the hand-written intersect kernel, else PT_ERR_UNSUPPORTED + why not

@@ -210,11 +210,16 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
 @pytest.mark.parametrize("name,W,H,kw,opts", [("C2", 96, 54, {}, {}), ("C2", 96, 54, {}, {"asm_loop": 1}), ("C3", 96, 54, {}, {}), ("C3", 96, 54, {}, {"asm_loop": 0}),
                                               ("C4", 64, 36, {}, {"asm_loop": 0}), ("C3", 96, 54, {}, {"extend_cache_bytes": 0, "refill_min": 1}),
                                               ("C3", 96, 54, {}, {"extend_cache_bytes": 60000, "refill_min": 64, "none_min": 1}),
-                                              ("C5", 64, 36, {"subdiv": 2}, {"inner_keep_eighths": 0}), ("C4", 64, 36, {}, {}), ("C5", 64, 36, {}, {"stack_mode": 1})])
+                                              ("C5", 64, 36, {"subdiv": 2}, {"inner_keep_eighths": 0}), ("C4", 64, 36, {}, {}), ("C5", 64, 36, {}, {"stack_mode": 1}),
+                                              ("C3", 96, 54, {}, {"asm_tpb": 1024}), ("C2", 96, 54, {}, {"asm_tpb": 1024}), ("C4", 64, 36, {}, {"asm_tpb": 1024}),
+                                              ("C5", 64, 36, {}, {"asm_tpb": 1024, "stack_mode": 1, "asm_loop": 0}),
+                                              ("C3", 96, 54, {}, {"asm_tpb": 1024, "extend_blocks_per_cu": 4, "extend_cache_bytes": 114688, "refill_min": 1})])
 def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
     """pt_extend_gfx950.s against the compiled kernels on 64 K rays per scene, a sixteenth of them irregular (zero, denormal, infinite, NaN
     components: the rays that take its min/max step): every hit record bit for bit.  C4 and the last case run its 18-bit-stack form;
-    asm_loop picks its main loop (0 phase-voting, 1 fused trip; automatic: fused unless the whole scene sits in the LDS tile, as C2 does)."""
+    asm_loop picks its main loop (0 phase-voting, 1 fused trip; automatic: fused unless the whole scene sits in the LDS tile, as C2 does);
+    asm_tpb its block size (1024 threads: what a context alone on its GPU launches once a launch is large enough; the last case one block
+    per CU with a 112 KB tile)."""
     wl = pt.scenes.build(name, W, H, **kw)
     o, d = mixed_regular_and_axis_parallel_rays(wl, 1 << 16, 11)
     r = renderer_mod.Renderer(W, H)
@@ -238,7 +243,9 @@ def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W,
 @pytest.mark.parametrize("name,W,H,frames,kw,opts", [("C2", 96, 54, 3, {}, {}), ("C3", 128, 72, 3, {}, {}), ("C3", 128, 72, 4, {}, {"path_slots": 2048}),
                                                      ("C3", 128, 72, 2, {}, {"path_slots": 1 << 16, "refill_min": 8}), ("C5", 64, 36, 2, {"subdiv": 2}, {}),
                                                      ("C4", 64, 36, 2, {}, {}), ("T1", 96, 54, 2, {}, {}), ("C3", 128, 72, 3, {}, {"asm_loop": 0}),
-                                                     ("C2", 96, 54, 2, {}, {"asm_loop": 1, "path_slots": 1024})])
+                                                     ("C2", 96, 54, 2, {}, {"asm_loop": 1, "path_slots": 1024}),
+                                                     ("C3", 128, 72, 3, {}, {"asm_tpb": 1024}), ("C3", 128, 72, 3, {}, {"asm_tpb": 1024, "path_slots": 2048}),
+                                                     ("C4", 64, 36, 2, {}, {"asm_tpb": 1024}), ("C5", 64, 36, 2, {"subdiv": 2}, {"asm_tpb": 1024})])
 def test_render_parity_handwritten_kernel(pt, oracle, renderer_mod, name, W, H, frames, kw, opts):
     """whole renders on the hand-written intersect kernel (statistics off: the counting variant is the compiled kernel) against the oracle,
     including the small pool that hands over to the device-packed tail queue"""
