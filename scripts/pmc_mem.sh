@@ -1,6 +1,6 @@
 #!/bin/bash
 # Memory-pipeline counters (TA / TCP / TD) of the two kernels, one stream so that each kernel has the chip to itself.
-# Each --pmc set in a run of its own, never combined with trace flags.
+# Each --pmc set in a run of its own, never combined with trace flags; at most four counters of one block per set (five TCP counters: rocprofv3 aborts).
 # usage: scripts/pmc_mem.sh <out-tag> <config> [extra bench.py flags]   -> gpurun_out/<out-tag>/mem_summary.txt
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-pmcmem}; CFG=${2:-C3}
@@ -16,9 +16,9 @@ for set in "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum SQ_INSTS_
            "TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_BUSY_avr TCP_GATE_EN2_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TA_TCP_STATE_READ_sum" \
            "TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
-           "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum"; do
+           "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/mem$i -- $BENCH > $OUT/mem$i.json 2> $OUT/mem$i.err || echo "set $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $OUT/mem$i -- $BENCH > $OUT/mem$i.json 2> $OUT/mem$i.err || echo "set $i failed"
   echo "pmc_mem $TAG set $i done"
 done
 python3 - $OUT <<'PY' > $OUT/mem_summary.txt
