@@ -71,6 +71,8 @@ def parse():
                     "opt-in relaxed one (hardware rcp/rsq/sqrt/log/cos in Box-Muller, normalize, 1/d, 1/det; per-pixel RMSE <= 1e-3, reported in the line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
+    ap.add_argument("--no-alone-pass", action="store_true", help="skip the one-stream pass after the timed region (roofline.frac then has no kernel-alone figure): "
+                    "for kernel traces whose per-kernel averages are to be compared with roofline.in_run")
     return ap.parse_args()
 
 
@@ -122,9 +124,10 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
         else:
             out.update({"achieved": None, "frac": None, "traffic": None})
         out["note"] = ("achieved / frac: the intersect kernel ALONE on the chip = SQ_INSTS_VALU per segment (committed rocprofv3 summary) x segments per launch / mean launch time (live HIP "
-                       "events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.  The kernel is bound by the latency of dependent node fetches "
-                       "at the hardware's 8 waves per SIMD, not by one pipe (DESIGN.md §2): the hand-written kernel issues a third fewer instructions per segment than the compiled one, "
-                       "which lowers this fraction while the segment rate rises.  lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
+                       "events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.  No single roof binds this kernel (DESIGN.md §2.1, profiles/r03_h_memory_pipe.txt): "
+                       "its dependent node fetches are hidden (a trip waits ~100 cycles for its records), the CU's vector-memory pipe is 66-76 % busy, VALU issue this fraction, the scalar "
+                       "unit about a third; the hand-written kernel issues a fifth fewer vector instructions per segment than the compiled one, which lowers this fraction while the segment "
+                       "rate rises.  lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
     else:
         out.update({"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": None, "traffic": None,
                     "note": f"no counter summary of {ext_kernel} in {prof_name}: run scripts/pmc_all.sh on a GPU box"})
@@ -401,7 +404,7 @@ def main():
         except renderer.PtError:
             ext_kernel = "k_extend_persist"
         alone = None
-        if multi and n_gpus == 1 and shards > 1 and rank == 0:
+        if multi and n_gpus == 1 and shards > 1 and rank == 0 and not args.no_alone_pass:
             # the kernels ALONE on the chip: two steps of the same workload on a one-stream context, after the timed region
             r1 = renderer.Renderer(W, H, device=devices[0])
             for name, val in (("extend_mode", args.extend_mode), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min), ("none_min", args.none_min),

@@ -14,8 +14,9 @@ timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_def
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c3_untimed_kernels.json 2>/dev/null
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 > $O/bench_c3_one_stream.json 2>/dev/null
 for cfg in C2 C4 C5; do timeout -k 10 600 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; done
-# 3. kernel trace + stats of the bench command (its average k_extend_persist duration must agree with the HIP-event figure)
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_trace.json 2> $O/bench_trace.err )
+# 3. kernel trace + stats of the bench command (the average pt_extend_asm duration must agree with the HIP-event figure roofline.in_run.avg_launch_ms;
+#    --no-alone-pass: without it the trace also holds the shorter launches of the one-stream pass that follows the timed region)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alone-pass > $O/bench_trace.json 2> $O/bench_trace.err )
 python3 - <<PY
 import csv, glob, json
 for f in glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True):
