@@ -471,7 +471,7 @@ def main():
         out["parity"] = {"gathered_image_bit_identical_to_one_gpu_render": bool(np.array_equal(got, ref, equal_nan=True)),
                          "sample": f"last step's gathered {W}x{H} image ({spp_step} spp) vs the same step rendered unsharded on one GPU"}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)      # before any teardown: the line is the product of the run
     r.close()
     if dist_mode:
         dist.destroy_process_group()

@@ -119,6 +119,11 @@ int multiRun(MultiCtx& M, const std::function<int(pt_ctx*)>& f) {
 void multiFree(pt_ctx* g) {
     MultiCtx* M = g->multi;
     if (!M) return;
+    // Order: nothing in flight on any device first; then the communicators, while the streams their collectives ran on still exist (RCCL keeps
+    // references to the user streams of its last operations); then the streams' contexts; the gather buffers last.
+    for (int d : std::set<int>(M->devices.begin(), M->devices.end())) { hipSetDevice(d); hipDeviceSynchronize(); }
+    if (!M->devices.empty()) hipSetDevice(M->devices[0]);
+    for (ncclComm_t& c : M->comms) if (c && g_rccl.CommDestroy) { g_rccl.CommDestroy(c); c = nullptr; }
     for (int i = 0; i < (int)M->kids.size(); i++) {
         pt_ctx* k = M->kids[i];
         if (i < (int)M->workers.size() && M->workers[i]) { M->workers[i]->post([k] { return pt_destroy(k); }); M->workers[i]->wait(); }
@@ -126,7 +131,6 @@ void multiFree(pt_ctx* g) {
     }
     for (auto& w : M->workers) if (w) { { std::lock_guard<std::mutex> lk(w->m); w->quit = true; w->cv.notify_all(); } if (w->th.joinable()) w->th.join(); }
     if (!M->devices.empty()) hipSetDevice(M->devices[0]);
-    for (ncclComm_t c : M->comms) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
     for (hipEvent_t e : M->ev) if (e) hipEventDestroy(e);
     for (void* p : {(void*)M->dGathered, (void*)M->dFull, (void*)M->dAllMaps}) if (p) hipFree(p);
     for (auto& r : M->runs) if (r.staging) { hipSetDevice(r.device); hipFree(r.staging); }

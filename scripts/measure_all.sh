@@ -14,21 +14,8 @@ timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_def
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c3_untimed_kernels.json 2>/dev/null
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 > $O/bench_c3_one_stream.json 2>/dev/null
 for cfg in C2 C4 C5; do timeout -k 10 600 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; done
-# 3. kernel trace + stats of the bench command (the average pt_extend_asm duration must agree with the HIP-event figure roofline.in_run.avg_launch_ms;
-#    --no-alone-pass: without it the trace also holds the shorter launches of the one-stream pass that follows the timed region)
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alone-pass > $O/bench_trace.json 2> $O/bench_trace.err )
-python3 - <<PY
-import csv, glob, json
-for f in glob.glob("$O/trace/**/*kernel_stats.csv", recursive=True):
-    print("name,calls,total_ms,avg_us,percent,min_us,max_us")
-    for row in csv.DictReader(open(f)):
-        n=row["Name"]; i=n.find("k_") if "pt_extend_asm" not in n else n.find("pt_extend_asm"); n=n[i:i+40] if i>=0 else n[:40]
-        print(f"{n},{row['Calls']},{float(row['TotalDurationNs'])/1e6:.3f},{float(row['AverageNs'])/1e3:.2f},{float(row['Percentage']):.3f},{float(row['MinNs'])/1e3:.2f},{float(row['MaxNs'])/1e3:.2f}")
-for l in open("$O/bench_trace.json"):
-    if l.startswith("{"):
-        d=json.loads(l); print("bench line of the traced run:", json.dumps({k:d[k] for k in ("value","ms_per_step","steps")}), json.dumps({k:d["roofline"]["in_run"][k] for k in ("avg_launch_ms","launches","frac")}), "shade avg", d["roofline"]["shade"]["in_run"]["avg_launch_ms"])
-PY
-rm -rf $O/trace
+# 3. kernel trace + stats of the bench command (scripts/trace_stats.sh)
+bash scripts/trace_stats.sh ${1:-measure}
 # 4. tile-shard rehearsals (one shard of N alone on this GPU) and the multi-GPU context with two shards on this GPU
 for n in 1 2 4 8; do timeout -k 10 300 python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --rehearse-shard 0 $n 2>/dev/null | python3 -c "
 import json,sys
