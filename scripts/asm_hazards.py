@@ -11,6 +11,9 @@ Checked (wait states = instructions issued in between; s_nop N counts N + 1):
   F  transcendental VALU              -> VALU reads its result                           1
   G  VMEM / DS store of > 8 B of data -> VALU writes one of the data registers           1   (2 with an SGPR offset; none here)
   H  VALU writes EXEC (v_cmpx)        -> v_readlane / v_readfirstlane / v_writelane      4
+and, along every path (branches followed both ways):
+  S  a scalar load (s_load / s_memtime) whose destination registers are read or written, or whose wave ends, before an s_waitcnt lgkmcnt(0):
+     scalar loads return out of order and nothing interlocks them — a register reused early is overwritten when the data lands.
 """
 import re
 import subprocess
@@ -124,14 +127,14 @@ def store_data(op, ops):
 
 def scan(path):
     text = subprocess.check_output([OBJDUMP, "-d", path], text=True)
-    ins = []
+    ins, raw = [], []
     for l in text.splitlines():
         if "//" not in l or not l.startswith("\t"):
             continue
         addr = l.split("//")[1].split(":")[0].strip()
         p = parse(l)
         if p:
-            ins.append((addr, l.split("//")[0].strip(), *p))
+            ins.append((addr, l.split("//")[0].strip(), *p)); raw.append(l)
     found = []
     for i, (addr, txt, op, ops) in enumerate(ins):
         kind, w, r = classify(op, ops)
@@ -164,6 +167,40 @@ def scan(path):
             states += (int(ops2[0], 0) + 1) if op2 == "s_nop" and ops2 else 1
             if op2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
                 break                                   # (what precedes a branch on the taken path is not in address order)
+    # S: path-sensitive walk from every scalar load to the first full lgkmcnt wait
+    index = {a: i for i, (a, *_rest) in enumerate(ins)}
+
+    def target(i):                                       # SOPP branch: target = address + 4 + 4 * simm16 (the low half of the instruction word)
+        a, word = raw[i].split("//")[1].split(":")
+        simm = int(word.split()[0], 16) & 0xffff
+        simm -= 0x10000 if simm & 0x8000 else 0
+        return index.get("%012X" % (int(a.strip(), 16) + 4 + 4 * simm))
+
+    for i, (addr, txt, op, ops) in enumerate(ins):
+        if not (op.startswith("s_load") or op.startswith("s_memtime") or op.startswith("s_buffer_load")):
+            continue
+        dest = regs(ops[0])
+        seen, work = set(), [(i + 1, 0)]
+        while work:
+            j, depth = work.pop()
+            while j is not None and j < len(ins) and j not in seen and depth < 400:
+                seen.add(j); depth += 1
+                a2, t2, op2, ops2 = ins[j]
+                if op2 == "s_waitcnt" and ("lgkmcnt(0)" in t2):
+                    break
+                k2, w2, r2 = classify(op2, ops2)
+                if op2.startswith("s_endpgm"):
+                    break                                # (s_endpgm waits for everything outstanding)
+                if (w2 | r2) & dest and not (k2 == "smem" and not (r2 & dest)):
+                    found.append(("S", 0, 0, addr, txt, a2, t2, sorted((w2 | r2) & dest)))
+                    break
+                if op2.startswith("s_branch"):
+                    j = target(j); continue
+                if op2.startswith("s_cbranch"):
+                    tj = target(j)
+                    if tj is not None:
+                        work.append((tj, depth))
+                j += 1
     return len(ins), found
 
 

@@ -38,6 +38,9 @@ def _assemble(tmp_path, body):
     ("  v_rcp_f32_e32 v1, v2\n  v_mul_f32_e32 v3, v1, v1", {"F"}),
     ("  global_store_dwordx4 v1, v[4:7], s[4:5]\n  v_mov_b32_e32 v5, 0", {"G"}),
     ("  v_readfirstlane_b32 s4, v1\n  s_nop 1\n  v_readlane_b32 s5, v2, s4", {"B"}),
+    # a scalar load still in flight when a branch leaves for code that reuses its registers (the round-3 refill bug: root boxes into s[64:71], the trip's masks)
+    ("  s_load_dwordx2 s[4:5], s[0:1], 0x0\n  s_cbranch_execz skip\n  s_waitcnt lgkmcnt(0)\n  s_mov_b32 s6, s4\nskip:\n  s_mov_b64 s[4:5], exec", {"S"}),
+    ("  s_load_dwordx2 s[4:5], s[0:1], 0x0\n  s_waitcnt lgkmcnt(0)\n  s_cbranch_execz skip\n  s_mov_b32 s6, s4\nskip:\n  s_mov_b64 s[4:5], exec", set()),
 ])
 def test_checker_finds_what_it_is_meant_to(tmp_path, body, rules):
     _, found = _checker().scan(_assemble(tmp_path, body))
