@@ -290,3 +290,13 @@ def test_part_group_path_of_a_two_rank_run():
         "g.close(); r1.close(); dist.destroy_process_group(); print('PART_OK')\n")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "PART_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_intersect_kernel_under_contention():
+    """scripts/contention_check.py in a process of its own: while two more contexts render C3 on the same GPU from threads of their own, the same 20 000 random
+    rays are traced 150 times on the hand-written kernel (block shape of the shared-GPU mode) and every hit record compared with the compiled kernel's.
+    The regime in which round 3's refill bug showed (scalar loads still in flight when the refill left for the trip: wild fetches once in a few hundred launches)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "contention_check.py"), "C3", "20000", "150"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert "0 launches with differences" in out.stdout
