@@ -60,7 +60,7 @@ int pt_create(pt_ctx** out, int device, int width, int height, int shard_rank, i
  *   {0,1,...,7}      all GPUs of the node, one stream each;
  *   {0,0}            TWO independent streams on one GPU — each with its own path pool and HIP stream, unsynchronised, so the intersect
  *                    kernel of one (issue/latency bound) overlaps the shading kernel of the other (HBM bound) and the launch tails fill:
- *                    12-25 % faster than one stream;
+ *                    11-24 % faster than one stream (round 3: C2 +11 %, C3 +14 %, C5 +19 %, C4 +24 %; profiles/r03_n_bench_*.json, r03_h_memory_pipe.txt (3));
  *   {0,0,1,1,...}    both (a device's entries adjacent, every device the same number of times).
  * Every entry point below works on it: uploads replicate the scene, the render calls render every stream's tile shard concurrently
  * (one host thread per stream inside the library), and pt_read_frame / pt_read_display / pt_gather_image perform the ONE collective

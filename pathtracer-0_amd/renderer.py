@@ -143,7 +143,7 @@ def shard_map(W, H, rank, count):
 
 class Renderer:
     """One render context.  `devices=[...]`: ONE context made of several wavefront streams (pt_create_multi): one entry per stream —
-    several GPUs ([0, 1, ...]), several independent streams on one GPU ([0, 0]: their kernels overlap, 9-24 % faster than one), or both
+    several GPUs ([0, 1, ...]), several independent streams on one GPU ([0, 0]: their kernels overlap, 11-24 % faster than one: include/pt_api.h), or both
     ([0, 0, 1, 1]); the tile shards, the per-stream host threads and the gather of every image live inside the library.
     first_shard / total_shards: the group renders only shards first_shard.. of total_shards (one process per GPU; pt_create_multi_part)."""
 
