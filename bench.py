@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C4", "C5", "C6"])
     ap.add_argument("--frames-per-step", type=int, default=None, help="frames (x SAMPLE_RES spp) per step; default = the config's full spp")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
@@ -76,14 +76,51 @@ def parse():
     return ap.parse_args()
 
 
-def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus=1, ext_kernel="k_extend_persist", alone=None):
-    """Per-kernel bounds, each recomputable from tracked files: the per-segment counter figures come from the committed rocprofv3
-    summary profiles/pmc_<config>.json (scripts/pmc_all.sh: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, FETCH_SIZE, WRITE_SIZE ... per
-    segment), the segments per launch and the launch durations are measured live (statistics pass + HIP events on the launch stream).
+def host_cores():
+    """(threads to use, what bounds them): the host's cores as far as this process may use them — os.cpu_count(), the affinity mask and the
+    cgroup CPU quota, whichever is smallest."""
+    total = os.cpu_count() or 1
+    info = {"cores_available": total}
+    n = total
+    try:
+        aff = len(os.sched_getaffinity(0))
+        info["affinity"] = aff
+        n = min(n, aff)
+    except Exception:
+        pass
+    quota = None
+    try:                                        # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                    # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        info["cgroup_cpu_quota"] = round(quota, 2)
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n), info
 
-    The top-level `frac` is ONE thing: the intersect kernel ALONE on the chip — its launches of the one-stream pass bench.py runs after
-    the timed region (`alone`; a run that is one stream anyway uses its own launches).  What one stream's launch reaches while it shares
-    the chip with the other streams' kernels sits under `in_run`, what the chip reaches with everything in flight under `chip`."""
+
+def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus=1, ext_kernel="k_extend_persist", alone=None):
+    """Bounds of the dominant kernel (the intersect kernel) and of the run, each recomputable from tracked files: the per-segment counter
+    figures come from the committed rocprofv3 summary profiles/pmc_<config>.json (scripts/pmc_all.sh: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU,
+    FETCH_SIZE, WRITE_SIZE ... per segment), the segments per launch and the launch durations are measured live (statistics pass + HIP events
+    on the launch streams).
+
+    Top level = the TIMED configuration, against the HBM roof, as SURVEY.md §8(d) / north_star define it:
+      achieved   §8(d)'s algorithmic bytes per segment of rayScene (44 B of queue traffic + 44 B per node visit + 36 B per triangle test
+                 + 124 B per hit update, the reference's buffer layout streamed from memory) x segments per launch / mean launch duration of
+                 the timed region.  The device-private BVH is served from LDS / L1 / L2, so this figure prices bytes that never reach HBM and
+                 may exceed the peak: `hbm` is the measured counterpart.
+      traffic    HBM bytes per launch from the counters (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction), per launch like `achieved`
+      hbm        rocprofv3 bytes of BOTH kernels over the wall time of the timed region, per GPU, against the 8 TB/s peak (north_star's figure),
+                 and each kernel's own launches beside it
+      valu_issue the roof the intersect kernel sits closest to (timed configuration and alone), `alone` the kernels alone on the chip."""
     n_ext, ms_ext = r.kernel_time("extend")
     n_sh, ms_sh = r.kernel_time("shade")
     S = stats["segments"] / max(stats["samples"], 1)
@@ -91,7 +128,7 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     nv, tt, hu = stats["nodes"] / stats["segments"], stats["tritests"] / stats["segments"], stats["hitupd"] / stats["segments"]
     avg_ext, avg_sh = ms_ext / max(n_ext, 1), ms_sh / max(n_sh, 1)       # mean launch over all devices' launches
     seg_per_launch = seg / max(n_ext, 1)
-    seg_rate = seg_per_launch / (avg_ext * 1e-3) if avg_ext > 0 else 0.0       # segments/s per device while the intersect kernel runs
+    seg_rate = seg_per_launch / (avg_ext * 1e-3) if avg_ext > 0 else 0.0       # segments/s per stream while the intersect kernel runs
     seg_rate_sh = (seg / max(n_sh, 1)) / (avg_sh * 1e-3) if avg_sh > 0 else 0.0
     prof, prof_name = None, f"profiles/pmc_{args.config}.json"
     if os.path.exists(os.path.join(ROOT, prof_name)):
@@ -102,65 +139,76 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     streams = max(world // max(n_gpus, 1), 1)
     if alone is None and streams == 1:
         alone = {"avg_ext_ms": avg_ext, "avg_shade_ms": avg_sh, "seg_per_launch": seg_per_launch, "launches": n_ext, "from": "the timed region (one stream per GPU)"}
-    out = {"kernel": ext_kernel, "counters_stale": bool(stale), "kernel_source_hash": src_hash,
-           "segments_per_sample": round(S, 3), "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3)}}
     ke = (prof or {}).get("kernels", {}).get(ext_kernel)
-    in_run = {"avg_launch_ms": round(avg_ext, 4), "median_launch_ms": round(r.kernel_time_median("extend"), 4), "launches": n_ext, "segments_per_launch": round(seg_per_launch),
-              "extend_share_of_step": round(ms_ext / max(world, 1) / (dt * 1e3), 3), "streams_per_gpu": streams}
-    if ke and "valu_per_segment" in ke:
-        vps = ke["valu_per_segment"]
-        in_run.update({"achieved": round(vps * seg_rate / 1e9, 1), "frac": round(vps * seg_rate / 1e9 / VALU_PEAK_GINST, 4)})
-        out.update({"bound": "valu_issue", "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "valu_insts_per_segment": vps, "salu_insts_per_segment": ke.get("salu_per_segment"),
-                    "lane_util": ke.get("lane_util"), "wait_share": ke.get("wait_share"), "issue_stall_share": ke.get("issue_stall_share"), "counters_from": prof_name})
-        if alone and alone["avg_ext_ms"] > 0:
-            rate = alone["seg_per_launch"] / (alone["avg_ext_ms"] * 1e-3)
-            out.update({"achieved": round(vps * rate / 1e9, 1), "frac": round(vps * rate / 1e9 / VALU_PEAK_GINST, 4), "avg_launch_ms": round(alone["avg_ext_ms"], 4),
-                        "segments_per_launch": round(alone["seg_per_launch"]), "launches": alone["launches"], "measured_in": alone["from"],
-                        "traffic": round(ke["hbm_bytes_per_segment"] * alone["seg_per_launch"]) if "hbm_bytes_per_segment" in ke else None})
-            if "hbm_bytes_per_segment" in ke:
-                gb = ke["hbm_bytes_per_segment"] * rate / 1e9
-                out["hbm"] = {"achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4), "bytes_per_segment": ke["hbm_bytes_per_segment"],
-                              "note": "measured FETCH_SIZE x2 + WRITE_SIZE per segment (gfx950 correction) x the kernel-alone segment rate"}
-        else:
-            out.update({"achieved": None, "frac": None, "traffic": None})
-        out["note"] = ("achieved / frac: the intersect kernel ALONE on the chip = SQ_INSTS_VALU per segment (committed rocprofv3 summary) x segments per launch / mean launch time (live HIP "
-                       "events on the launch stream); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.  No single roof binds this kernel (DESIGN.md §2.1, profiles/r03_h_memory_pipe.txt): "
-                       "its dependent node fetches are hidden (a trip waits ~100 cycles for its records), the CU's vector-memory pipe is 66-76 % busy, VALU issue this fraction, the scalar "
-                       "unit about a third; the hand-written kernel issues a fifth fewer vector instructions per segment than the compiled one, which lowers this fraction while the segment "
-                       "rate rises.  lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES")
-    else:
-        out.update({"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": None, "traffic": None,
-                    "note": f"no counter summary of {ext_kernel} in {prof_name}: run scripts/pmc_all.sh on a GPU box"})
-    out["in_run"] = in_run
     ks = (prof or {}).get("kernels", {}).get("k_shade")
-    sh = {"kernel": "k_shade", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-          "in_run": {"avg_launch_ms": round(avg_sh, 4), "median_launch_ms": round(r.kernel_time_median("shade"), 4), "shade_share_of_step": round(ms_sh / max(world, 1) / (dt * 1e3), 3)}}
-    if ks and "hbm_bytes_per_segment" in ks:
-        sh["in_run"].update({"achieved": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9, 1), "frac": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4)})
-        sh.update({"bytes_per_segment": ks["hbm_bytes_per_segment"], "lane_util": ks.get("lane_util"), "counters_from": prof_name})
-        if alone and alone["avg_shade_ms"] > 0:
-            gb = ks["hbm_bytes_per_segment"] * alone["seg_per_launch"] / (alone["avg_shade_ms"] * 1e-3) / 1e9
-            sh.update({"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBS, 4), "avg_launch_ms": round(alone["avg_shade_ms"], 4),
-                       "traffic": round(ks["hbm_bytes_per_segment"] * alone["seg_per_launch"]), "measured_in": alone["from"]})
-    out["shade"] = sh
-    # SURVEY.md §8(d)'s algorithmic figure (the reference's buffer layout streamed from memory), kept as a labelled secondary number:
-    # the device-private BVH is served from LDS and L2, so this is NOT a fraction of any roof of this kernel
+    # algorithmic bytes per segment of the intersect kernel / per sample of the whole path, in the reference's layout
     b_ext = Q_EXTEND + nv * 44 + tt * 36 + hu * 124
     b_samp = S * 304 + S * (nv * 44 + tt * 36 + hu * 124) + 32.0 / sample_res
-    # what the chip reaches with everything in flight: total instructions / bytes of the timed region over its wall time, per GPU
-    if ke and ks and "valu_per_segment" in ke and "valu_per_segment" in ks:
-        v = (ke["valu_per_segment"] + ks["valu_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
-        chip = {"streams_per_gpu": streams, "kernel_concurrency": round((ms_ext + ms_sh) / (dt * 1e3) / max(n_gpus, 1), 3),
-                "valu_issue": {"achieved": round(v, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": round(v / VALU_PEAK_GINST, 4)},
-                "note": f"whole timed region, both kernels: (VALU instructions per segment of {ext_kernel} + k_shade) x segments / wall time / GPUs; likewise HBM bytes"}
-        if "hbm_bytes_per_segment" in ke and "hbm_bytes_per_segment" in ks:
-            b = (ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
-            chip["hbm"] = {"achieved": round(b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / HBM_PEAK_GBS, 4)}
-        out["chip"] = chip
-    out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "extend_GBps_if_streamed": round(b_ext * seg_rate / 1e9, 1),
-                          "bytes_per_sample_whole_path": round(b_samp, 1), "whole_path_GBps_per_gpu": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1), 1),
-                          "note": "SURVEY.md 8(d): 44 B per node visit, 36 B per triangle test, 124 B per hit update, 304 B of queue state per segment in the reference's "
-                                  "layout; a bookkeeping figure, not a roofline fraction"}
+    gbs = b_ext * seg_rate / 1e9
+    out = {"bound": "hbm", "kernel": ext_kernel, "configuration": f"the timed region: {streams} stream(s) per GPU, {n_gpus} GPU(s)",
+           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "traffic": round(ke["hbm_bytes_per_segment"] * seg_per_launch) if ke and "hbm_bytes_per_segment" in ke else None,
+           "algorithmic_bytes_per_segment": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * seg_per_launch),
+           "segments_per_launch": round(seg_per_launch), "avg_launch_ms": round(avg_ext, 4), "median_launch_ms": round(r.kernel_time_median("extend"), 4), "launches": n_ext,
+           "extend_share_of_step": round(ms_ext / max(world, 1) / (dt * 1e3), 3), "streams_per_gpu": streams,
+           "counters_stale": bool(stale), "kernel_source_hash": src_hash, "counters_from": prof_name if prof else None,
+           "segments_per_sample": round(S, 3), "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3)},
+           "note": ("achieved = SURVEY.md 8(d)'s algorithmic bytes per segment (44 B queue + 44 B per node visit + 36 B per triangle test + 124 B per hit update, the reference's "
+                    "layout streamed from memory) x segments per launch / mean launch duration of the timed region (HIP events on the launch streams).  The device-private BVH is "
+                    "served from LDS / L1 / L2, so these bytes mostly never reach HBM (frac may exceed 1 for a cache-resident tree): `traffic` and `hbm` are the measured bytes.")}
+    # ---- measured HBM bytes (north_star: rocprof achieved HBM GB/s against the chip's 8 TB/s)
+    hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "note": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction) per segment from the committed counter summary x the segments of the "
+                                                            "timed region: both kernels over the wall time per GPU, and each kernel over its own launches"}
+    if ke and ks and "hbm_bytes_per_segment" in ke and "hbm_bytes_per_segment" in ks:
+        b = (ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
+        hbm.update({"achieved": round(b, 1), "frac": round(b / HBM_PEAK_GBS, 4), "bytes_per_segment": round(ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"], 2),
+                    "bytes_per_sample": round((ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * S + 32.0 / sample_res, 1),
+                    "algorithmic_queue_bytes_per_sample": round(S * 304 + 32.0 / sample_res, 1),
+                    ext_kernel: {"bytes_per_segment": ke["hbm_bytes_per_segment"], "achieved": round(ke["hbm_bytes_per_segment"] * seg_rate / 1e9, 1),
+                                 "frac": round(ke["hbm_bytes_per_segment"] * seg_rate / 1e9 / HBM_PEAK_GBS, 4)},
+                    "k_shade": {"bytes_per_segment": ks["hbm_bytes_per_segment"], "achieved": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9, 1),
+                                "frac": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4)}})
+    else:
+        hbm.update({"achieved": None, "frac": None, "note": f"no counter summary in {prof_name}: run scripts/pmc_all.sh on a GPU box"})
+    out["hbm"] = hbm
+    # ---- the intersect kernel against VALU issue (the roof it sits closest to)
+    vi = {"peak": VALU_PEAK_GINST, "unit": "Ginst/s", "note": "SQ_INSTS_VALU per segment (committed rocprofv3 summary) x segments per launch / mean launch time; peak = 256 CUs x 4 SIMDs x "
+                                                               "2.4 GHz / 2 cycles per wave64 instruction; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
+    if ke and "valu_per_segment" in ke:
+        vps = ke["valu_per_segment"]
+        vi.update({"valu_insts_per_segment": vps, "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"), "wait_share": ke.get("wait_share"),
+                   "issue_stall_share": ke.get("issue_stall_share"), "achieved": round(vps * seg_rate / 1e9, 1), "frac": round(vps * seg_rate / 1e9 / VALU_PEAK_GINST, 4)})
+        if ks and "valu_per_segment" in ks:
+            v = (vps + ks["valu_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
+            vi["chip"] = {"achieved": round(v, 1), "frac": round(v / VALU_PEAK_GINST, 4), "kernel_concurrency": round((ms_ext + ms_sh) / (dt * 1e3) / max(n_gpus, 1), 3)}
+    out["valu_issue"] = vi
+    # ---- the kernels ALONE on the chip (a one-stream pass after the timed region)
+    if alone and alone["avg_ext_ms"] > 0:
+        rate = alone["seg_per_launch"] / (alone["avg_ext_ms"] * 1e-3)
+        al = {"measured_in": alone["from"], "avg_launch_ms": round(alone["avg_ext_ms"], 4), "segments_per_launch": round(alone["seg_per_launch"]), "launches": alone["launches"],
+              "algorithmic": {"achieved": round(b_ext * rate / 1e9, 1), "frac": round(b_ext * rate / 1e9 / HBM_PEAK_GBS, 4)}}
+        if ke and "valu_per_segment" in ke:
+            al["valu_issue"] = {"achieved": round(ke["valu_per_segment"] * rate / 1e9, 1), "frac": round(ke["valu_per_segment"] * rate / 1e9 / VALU_PEAK_GINST, 4)}
+        if ke and "hbm_bytes_per_segment" in ke:
+            al["hbm"] = {"achieved": round(ke["hbm_bytes_per_segment"] * rate / 1e9, 1), "frac": round(ke["hbm_bytes_per_segment"] * rate / 1e9 / HBM_PEAK_GBS, 4)}
+        if alone.get("avg_shade_ms", 0) > 0:
+            al["k_shade"] = {"avg_launch_ms": round(alone["avg_shade_ms"], 4)}
+            if ks and "hbm_bytes_per_segment" in ks:
+                gb = ks["hbm_bytes_per_segment"] * alone["seg_per_launch"] / (alone["avg_shade_ms"] * 1e-3) / 1e9
+                al["k_shade"]["hbm"] = {"achieved": round(gb, 1), "frac": round(gb / HBM_PEAK_GBS, 4)}
+        if alone.get("counters_note"):
+            al["counters_note"] = alone["counters_note"]
+        out["alone"] = al
+    sh = {"kernel": "k_shade", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(avg_sh, 4), "median_launch_ms": round(r.kernel_time_median("shade"), 4),
+          "shade_share_of_step": round(ms_sh / max(world, 1) / (dt * 1e3), 3), "algorithmic_bytes_per_segment": 260,
+          "algorithmic": {"achieved": round(260 * seg_rate_sh / 1e9, 1), "frac": round(260 * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4)}}
+    if ks and "hbm_bytes_per_segment" in ks:
+        sh.update({"achieved": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9, 1), "frac": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4),
+                   "bytes_per_segment": ks["hbm_bytes_per_segment"], "traffic": round(ks["hbm_bytes_per_segment"] * seg / max(n_sh, 1)), "lane_util": ks.get("lane_util")})
+    out["shade"] = sh
+    out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "bytes_per_sample_whole_path": round(b_samp, 1),
+                          "whole_path_GBps_per_gpu": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1), 1), "whole_path_frac": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1) / HBM_PEAK_GBS, 4),
+                          "note": "SURVEY.md 8(d): B = S*304 + S*(Nv*44 + Tt*36 + Hu*124) + 32/SAMPLE_RES per sample x samples/s per GPU; S, Nv, Tt, Hu from the statistics pass (equal to the oracle's)"}
     return out
 
 
@@ -421,15 +469,30 @@ def main():
             na, msa = r1.kernel_time("extend"); ns, mss = r1.kernel_time("shade")
             S_ = stats["segments"] / max(stats["samples"], 1)
             alone = {"avg_ext_ms": msa / max(na, 1), "avg_shade_ms": mss / max(ns, 1), "seg_per_launch": S_ * 2.0 * len(seeds_a) * sample_res * W * H / max(na, 1), "launches": na,
-                     "from": f"a one-stream pass after the timed region: 2 x {len(seeds_a)} frames of the same workload, the kernels alone on the chip"}
+                     "from": f"a one-stream pass after the timed region: 2 x {len(seeds_a)} frames of the same workload, the kernels alone on the chip",
+                     "counters_note": "per-segment counter figures are those of the committed summary (two streams per GPU, 256-thread intersect blocks); alone on its GPU the intersect "
+                                      "kernel runs 1024-thread blocks, whose counters differ by about 1 % in VALU and 4 % in HBM bytes per segment (profiles/r03_m_pmc_C3_one_stream.txt)"}
             r1.close()
         out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res, n_gpus=n_gpus, ext_kernel=ext_kernel, alone=alone)
 
+    if rank == 0 and full is not None and hasattr(full, "cpu") and not args.rehearse_shard:
+        # SURVEY.md 8(d) ends the clock at the completion of pt_read_frame; `value` ends at the gathered image in HBM (results resident, like the inputs).
+        # The read-back of one image over PCIe, measured here after the timed region (pinned host memory), and the rate with one read-back per step added:
+        host = torch.empty(full.shape, dtype=full.dtype, pin_memory=True)
+        torch.cuda.synchronize(full.device)
+        tr = time.perf_counter()
+        for _ in range(3):
+            host.copy_(full, non_blocking=True)
+        torch.cuda.synchronize(full.device)
+        rb = (time.perf_counter() - tr) / 3.0
+        out["readback"] = {"ms_per_image": round(rb * 1e3, 3), "bytes": int(full.numel() * full.element_size()),
+                           "value_with_one_readback_per_step": round(samples / (dt + rb * args.steps) / 1e6, 3),
+                           "note": "value ends at the gathered image in device memory; pt_read_frame adds this copy (not overlapped here: an upper bound on its cost)"}
     if rank == 0 and n_gpus == 1 and not dist_mode and not args.rehearse_shard and not args.no_cpu_baseline:
         # the reference has no CPU render path: the timed CPU baseline is the oracle ("port")
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle
-        cores = min(os.cpu_count() or 1, 16)
+        cores, core_info = host_cores()         # every core this process may use (affinity mask, cgroup quota)
         sc = oracle.Scene.from_workload(wl)
         xs = ys = 2 if W * H > 3000000 else 1
         buf = np.zeros((H, W, 4), dtype=np.float32)
@@ -454,7 +517,7 @@ def main():
                          "sample": f"frames 1..{nfr} of the timed workload ({nfr * sample_res} spp), every {xs}th pixel in x and y"
                                    + (" — the relaxed contract is not bit-identical by design; at the workload's full spp its RMSE is what tests/test_gpu_parity.py::test_fast_contract_rmse asserts"
                                       if args.contract == "fast" else "")}
-        out["cpu_baseline"] = {"value": round(csamp / tcpu / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        out["cpu_baseline"] = {"value": round(csamp / tcpu / 1e6, 3), "unit": "Msamples/s", "cores": cores, **core_info, "kind": "port",
                                "sample": f"oracle (C++ restatement of frag.glsl), frames 1..{nfr} ({sample_res} spp each) of the same workload at every {xs}th pixel in x and y: "
                                          f"{int(csamp)} samples in {tcpu:.2f} s"}
     elif rank == 0 and (multi or dist_mode) and full is not None and not args.no_cpu_baseline:

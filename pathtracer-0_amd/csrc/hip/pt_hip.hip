@@ -843,7 +843,7 @@ struct pt_ctx {
     uint64_t asmLaunches = 0;
     bool asmEligible = false;       // this scene can run on the hand-written kernel (buildScene)
     std::string asmWhyNot;          // ... or why not (pt_debug: reported by option 12)
-    hipModule_t asmModule[8] = {}; hipFunction_t asmFn[8] = {};      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract); [4..7] the same four with 1024-thread blocks
+    hipModule_t asmModule[8] = {}; hipFunction_t asmFn[8] = {}; std::string asmLoadError[8];      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract); [4..7] the same four with 1024-thread blocks
     int asmTpb = 0;                 // threads per block of the hand-written kernel: 0 automatic (launchExtendAsm), 256, 1024
     bool debugExactExtend = false;  // pt_debug_intersect always probes the exact kernels
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
@@ -1205,14 +1205,22 @@ static_assert(sizeof(EpAsmArgs) == 120, "EpAsmArgs layout is part of the assembl
 #endif
 #include PT_EXTEND_INC              // the assembled code objects (build.py): pt_extend_hsaco_s16[], pt_extend_hsaco_p18[]
 
-int loadAsmKernel(pt_ctx* c) {
-    if (c->asmFn[7]) return 0;
+// One code object per variant, loaded when a launch first needs it (a stream uses one or two of the eight).  A variant that failed to load stays
+// failed: the error is latched, nothing half-loaded is kept and later launches do not retry.
+int loadAsmKernel(pt_ctx* c, int k) {
+    if (c->asmFn[k]) return 0;
+    if (!c->asmLoadError[k].empty()) return fail(PT_ERR_HIP, c->asmLoadError[k]);
     const void* images[8] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f,
                              pt_extend_hsaco_s16w, pt_extend_hsaco_p18w, pt_extend_hsaco_s16fw, pt_extend_hsaco_p18fw};
-    for (int k = 0; k < 8; k++) {
-        HIP_TRY(hipModuleLoadData(&c->asmModule[k], images[k]));
-        HIP_TRY(hipModuleGetFunction(&c->asmFn[k], c->asmModule[k], "pt_extend_asm"));
+    hipModule_t m = nullptr; hipFunction_t f = nullptr;
+    hipError_t e = hipModuleLoadData(&m, images[k]);
+    if (e == hipSuccess) e = hipModuleGetFunction(&f, m, "pt_extend_asm");
+    if (e != hipSuccess) {
+        if (m) hipModuleUnload(m);
+        c->asmLoadError[k] = std::string("code object ") + std::to_string(k) + " of pt_extend_asm: " + hipGetErrorString(e);
+        return fail(PT_ERR_HIP, c->asmLoadError[k]);
     }
+    c->asmModule[k] = m; c->asmFn[k] = f;
     return 0;
 }
 
@@ -1255,7 +1263,8 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     int perCU = std::max(1, std::min((int)(ldsPerCU / lds), maxBlocks));
     int grid = c->numCUs * perCU;
     grid = std::max(1, std::min(grid, ((int)pr.launched + TPB - 1) / TPB));
-    if (loadAsmKernel(c)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
+    const int variant = (c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0) + (TPB == 1024 ? 4 : 0);
+    if (loadAsmKernel(c, variant)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
     a.numObj = sc.numObj; a.iter = pr.iter; a.nSlots = (int)pr.launched; a.refillMin = c->refillMin; a.keepEighths = c->innerKeepEighths; a.noneMin = c->noneMin;
@@ -1265,11 +1274,13 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     a.mode = c->asmLoop >= 0 ? (unsigned)c->asmLoop : (allInLds ? 0u : 1u);
     if (a.mode && !c->noneMinSet) a.noneMin = 2;      // the fused loop serves lanes that wait for their next BVH sooner (C3 +1.8 %, C5 +1 %, C4 / one stream +-0: profiles/r03_c_main_loops.txt (8))
     a.nWaves = (unsigned)grid * (unsigned)(TPB / 64);
-    if (getenv("PT_ASM_DEBUG")) {
+#ifdef PT_ASM_DEBUG                  // developer builds only (scripts/build_variant.py -DPT_ASM_DEBUG): the per-wave debug records of the assembly
+    {
         if (!c->dAsmDbg) { if (hipMalloc(&c->dAsmDbg, 8192 * 64) != hipSuccess) return false; }
         hipMemsetAsync(c->dAsmDbg, 0xff, 8192 * 64, pr.stream);
         a.dbg = c->dAsmDbg;
     }
+#endif
     {   // x / nWaves == mulhi(x, divM) >> divS for x < 2^31 (nWaves >= 4)
         unsigned d = a.nWaves; int l = 0;
         while ((1ull << l) < d) l++;
@@ -1277,7 +1288,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     }
     size_t asz = sizeof(a);
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-    const hipError_t e = hipModuleLaunchKernel(c->asmFn[(c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0) + (TPB == 1024 ? 4 : 0)], (unsigned)grid, 1, 1, (unsigned)TPB, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
+    const hipError_t e = hipModuleLaunchKernel(c->asmFn[variant], (unsigned)grid, 1, 1, (unsigned)TPB, 1, 1, (unsigned)lds, pr.stream, nullptr, extra);
     if (e != hipSuccess) { c->asmError = std::string("hipModuleLaunchKernel(pt_extend_asm): ") + hipGetErrorString(e); return false; }
     c->asmLaunches++;
     return true;
@@ -1929,11 +1940,14 @@ int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out
 
 namespace {
 // minimal PNG writer: IHDR + one IDAT of stored (uncompressed) deflate blocks + IEND
+struct Crc32Table {
+    uint32_t T[256];
+    constexpr Crc32Table() : T{} { for (uint32_t i = 0; i < 256; i++) { uint32_t x = i; for (int k = 0; k < 8; k++) x = (x & 1) ? 0xedb88320u ^ (x >> 1) : x >> 1; T[i] = x; } }
+};
+constexpr Crc32Table kCrc32{};      // built at compile time: contexts may write PNGs from different threads at once
 uint32_t crc32_(const uint8_t* p, size_t n, uint32_t c) {
-    static uint32_t T[256]; static bool init = false;
-    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t x = i; for (int k = 0; k < 8; k++) x = (x & 1) ? 0xedb88320u ^ (x >> 1) : x >> 1; T[i] = x; } init = true; }
     c = ~c;
-    for (size_t i = 0; i < n; i++) c = T[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    for (size_t i = 0; i < n; i++) c = kCrc32.T[(c ^ p[i]) & 0xff] ^ (c >> 8);
     return ~c;
 }
 void pngChunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
@@ -1943,7 +1957,7 @@ void pngChunk(std::vector<uint8_t>& out, const char* type, const std::vector<uin
     out.insert(out.end(), type, type + 4); out.insert(out.end(), data.begin(), data.end());
     be32(crc32_(out.data() + at, out.size() - at, 0));
 }
-std::vector<uint8_t> encodePng(const uint8_t* rgb, int W, int H) {
+static std::vector<uint8_t> encodePng(const uint8_t* rgb, int W, int H) {
     std::vector<uint8_t> raw; raw.reserve((size_t)H * (3 * (size_t)W + 1));
     for (int y = 0; y < H; y++) { raw.push_back(0); raw.insert(raw.end(), rgb + (size_t)y * W * 3, rgb + (size_t)(y + 1) * W * 3); }      // filter type 0 per scanline
     std::vector<uint8_t> z = {0x78, 0x01};
@@ -2222,11 +2236,13 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float> h(np * 4);
     HIP_TRY(hipMemcpy(h.data(), st.H, np * 16, hipMemcpyDeviceToHost));
-    if (c->dAsmDbg && getenv("PT_ASM_DEBUG")) {
+#ifdef PT_ASM_DEBUG
+    if (c->dAsmDbg) {
         std::vector<unsigned> dbg(8192 * 16);
         HIP_TRY(hipMemcpy(dbg.data(), c->dAsmDbg, dbg.size() * 4, hipMemcpyDeviceToHost));
         for (int w = 0; w < 24; w++) { fprintf(stderr, "asm wave %d:", w); for (int k = 0; k < 9; k++) fprintf(stderr, " %u", dbg[16 * w + k]); fprintf(stderr, "\n"); }
     }
+#endif
     std::memcpy(out, h.data(), n * 16);
     return PT_OK;
 }

@@ -20,6 +20,8 @@ CONFIGS = {
     "C3": dict(W=1920, H=1080, spp=256, bounces=8, sample_res=8),
     "C4": dict(W=1920, H=1080, spp=1024, bounces=8, sample_res=8),
     "C5": dict(W=3840, H=2160, spp=4096, bounces=16, sample_res=8),
+    # not a BASELINE config: the shape of the reference author's own scenes (multi-group OBJs + addEllipsoid, dispatch.java:245-264)
+    "C6": dict(W=1920, H=1080, spp=256, bounces=8, sample_res=8),
 }
 
 
@@ -449,7 +451,45 @@ def asset_workload(directory, W, H, cam=CORNELL_CAM, rot=CORNELL_ROT, sky=(30, 4
     return wl
 
 
-BUILDERS = {"C1": c1_spheres, "C2": c2_cornell, "C3": c3_glass_metal, "C4": c4_mesh, "C5": c5_clearcoat_sss}
+def c6_many_objects(W=1920, H=1080, sample_res=8, max_bounces=8, groups=64, nu=28, nv=28, seed=6):
+    """C6: the shape of the scenes the reference's author lists (dispatch.java:245-264: multi-group OBJs with dozens of `o` groups — one BVH
+    each, frag.glsl:563-577 loops over all of them — next to addEllipsoid calls): the Cornell room's two groups + (groups - 2) seeded
+    displaced tori of 2*nu*nv triangles each in a 4x4x4 lattice (64 groups: 97 228 triangles), materials cycling through diffuse / metal /
+    glass / clearcoat, plus 3 ellipsoids (one stretched, one rotated)."""
+    sc = _new_scene()
+    _cornell_materials(sc)
+    names = []
+    for k, (kd, extra) in enumerate([((0.7, 0.55, 0.4), {}), ((0.9, 0.8, 0.5), dict(Pm=1, Pr=0.1)), ((0.9, 0.9, 0.9), dict(Tr=0.9, Ni=1.5, Tf=(0.05, 0.2, 0.05), Density=1)),
+                                     ((0.1, 0.2, 0.7), dict(Ks=(0.9, 0.9, 0.9), Pc=0.5, Pcr=0.1)), ((0.3, 0.6, 0.35), {}), ((0.6, 0.3, 0.6), dict(Pm=0.5, Pr=0.4))]):
+        names.append(f"m{k}")
+        sc.addMaterial(names[-1])
+        sc.setLastMtl("Kd", kd)
+        sc.setLastMtl("Pr", 1)
+        for key, val in extra.items():
+            sc.setLastMtl(key, val)
+    o = Obj()
+    _cornell_room(o, boxes=False)
+    rs = np.random.RandomState(seed)
+    cells = [(i, j, k) for k in range(4) for j in range(4) for i in range(4)]
+    for g in range(groups - 2):
+        i, j, k = cells[g % len(cells)]
+        centre = np.array((-0.75 + 0.5 * i, 0.25 + 0.48 * j, -0.75 + 0.5 * k)) + rs.uniform(-0.04, 0.04, size=3)
+        v, n, f = displaced_torus(nu, nv, (0.0, 0.0, 0.0), 0.13, 0.055, 0.25, seed * 1000 + g)
+        a, b = rs.uniform(0, math.pi, size=2)
+        Rx = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+        Ry = np.array([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]])
+        M = Ry @ Rx
+        o.group(f"torus{g}")
+        o.usemtl(names[g % len(names)])
+        o.mesh([tuple(M @ np.array(p) + centre) for p in v], [tuple(M @ np.array(q)) for q in n], f)
+    sc.addObjectText(o.text(), 0, parentDirectory="")
+    sc.addEllipsoid((0.0, 1.0, 0.0), 1, 0, 0.16, 5)
+    sc.addEllipsoid((0.5, 0.75, -0.5), (1.0, 2.5, 1.0), 0, 0.12, 4)
+    sc.addEllipsoid((-0.5, 1.25, 0.5), (2.0, 1.0, 1.0), (0.3, 0.2, 0.1), 0.14, 7)
+    return _finish("C6", sc, W, H, CORNELL_CAM, CORNELL_ROT, (0, 0, 0), sample_res, max_bounces)
+
+
+BUILDERS = {"C1": c1_spheres, "C2": c2_cornell, "C3": c3_glass_metal, "C4": c4_mesh, "C5": c5_clearcoat_sss, "C6": c6_many_objects}
 
 
 def build(name, W=None, H=None, **kw):

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Static scan of the assembled intersect kernel for the gfx940-family hazards the assembler does not pad (LLVM's GCNHazardRecognizer inserts the
-s_nops for compiled code; hand-written code has to carry them).  Works on the disassembly of a code object, in address order (fall-through paths):
+s_nops for compiled code; hand-written code has to carry them).  Works on the disassembly of a code object as a control-flow graph: every rule is
+evaluated along EVERY path, forwards through both outcomes of a conditional branch, backwards through every predecessor of a label (taken branches
+and loop back-edges included):
     asm_hazards.py [build/asm/pt_extend_hsaco/pt_extend_s16.hsaco ...]
-Checked (wait states = instructions issued in between; s_nop N counts N + 1):
+Wait-state rules (wait states = instructions issued in between on the path; s_nop N counts N + 1):
   A  VALU writes an SGPR / VCC        -> VALU reads it as an operand or mask            2
   B  VALU writes an SGPR / VCC        -> v_readlane / v_writelane lane select            4
   C  VALU writes VCC                  -> v_div_fmas                                      4
@@ -11,9 +13,14 @@ Checked (wait states = instructions issued in between; s_nop N counts N + 1):
   F  transcendental VALU              -> VALU reads its result                           1
   G  VMEM / DS store of > 8 B of data -> VALU writes one of the data registers           1   (2 with an SGPR offset; none here)
   H  VALU writes EXEC (v_cmpx)        -> v_readlane / v_readfirstlane / v_writelane      4
-and, along every path (branches followed both ways):
+Memory-return rules (forward walk from every load, no depth limit: a walk ends at a covering wait, at s_endpgm or where it has been before):
   S  a scalar load (s_load / s_memtime) whose destination registers are read or written, or whose wave ends, before an s_waitcnt lgkmcnt(0):
      scalar loads return out of order and nothing interlocks them — a register reused early is overwritten when the data lands.
+  V  a vector-memory load (vmcnt) or an LDS read (lgkmcnt) whose destination VGPRs are read, or written by anything but another load, before an
+     s_waitcnt that covers it.  Loads of one counter return in issue order, so a load with k younger operations of its counter issued behind it is
+     complete after s_waitcnt <counter>(N) with N <= k: the walk carries k (the minimum over the paths that meet).  Another load into the same
+     registers is not a touch (the two arms of a fetch write disjoint lanes of the same registers and share one wait).
+  X  the scan itself could not follow a path (a branch whose target is not an instruction of the object): reported, never skipped.
 """
 import re
 import subprocess
@@ -21,6 +28,7 @@ import sys
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_log_", "v_exp_", "v_sin_", "v_cos_", "v_rcp_iflag")
+MAX_NEED = 5          # the longest wait-state requirement above
 
 
 def regs(tok):
@@ -74,6 +82,8 @@ def classify(op, ops):
             w |= regs(ops[0]) if ops else set(); srcs = ops[1:]
         for t in srcs:
             r |= regs(t)
+        if op.startswith(("v_fmac_", "v_mac_", "v_pk_fmac", "v_dot2c", "v_dot4c", "v_dot8c")):
+            r |= w                                          # the destination is also the accumulator
         if op.startswith(("v_cndmask_b32_e32", "v_addc_co_u32_e32", "v_subb_co_u32_e32", "v_div_fmas")) or (op.startswith("v_cndmask") and len(ops) == 3):
             r |= {"vcc_lo", "vcc_hi"}
         return kind, w, r
@@ -101,7 +111,7 @@ def classify(op, ops):
             r |= regs(t)
         return "smem", w, r
     if op.startswith("s_"):
-        if op.startswith(("s_cmp", "s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_barrier", "s_endpgm", "s_setprio", "s_bitcmp")):
+        if op.startswith(("s_cmp", "s_cbranch", "s_branch", "s_waitcnt", "s_nop", "s_barrier", "s_endpgm", "s_setprio", "s_bitcmp", "s_sleep")):
             for t in ops:
                 r |= regs(t)
             return "salu", w, r
@@ -125,82 +135,197 @@ def store_data(op, ops):
     return set()
 
 
-def scan(path):
-    text = subprocess.check_output([OBJDUMP, "-d", path], text=True)
-    ins, raw = [], []
-    for l in text.splitlines():
-        if "//" not in l or not l.startswith("\t"):
-            continue
-        addr = l.split("//")[1].split(":")[0].strip()
-        p = parse(l)
-        if p:
-            ins.append((addr, l.split("//")[0].strip(), *p)); raw.append(l)
-    found = []
-    for i, (addr, txt, op, ops) in enumerate(ins):
-        kind, w, r = classify(op, ops)
-        # look back
-        states = 0
-        for j in range(i - 1, max(i - 8, -1), -1):
-            a2, t2, op2, ops2 = ins[j]
-            k2, w2, r2 = classify(op2, ops2)
-            def hit(rule, need, regs_):
-                if regs_ and states < need:
-                    found.append((rule, need, states, a2, t2, addr, txt, sorted(regs_)))
-            sg = {x for x in w2 if x[0] == "s" or x.startswith("vcc")} if k2 == "valu" else set()
-            if kind == "valu":
-                lane_sel = op.startswith(("v_readlane", "v_writelane"))
-                if lane_sel and ops:
-                    hit("B", 4, sg & regs(ops[-1]))
-                hit("A", 2, sg & r)
-                if op.startswith("v_div_fmas"):
-                    hit("C", 4, sg & {"vcc_lo", "vcc_hi"})
-                if op.startswith(("v_readfirstlane", "v_readlane")) and k2 == "valu":
-                    hit("E", 1, {x for x in w2 if x[0] == "v"} & r)
-                if k2 == "valu" and op2.startswith(TRANS):
-                    hit("F", 1, {x for x in w2 if x[0] == "v"} & r)
-                if k2 in ("vmem", "ds"):
-                    hit("G", 1, store_data(op2, ops2) & w)
-                if op.startswith(("v_readfirstlane", "v_readlane", "v_writelane")) and k2 == "valu" and op2.startswith("v_cmpx"):
-                    hit("H", 4, {"exec"})
-            if kind in ("vmem", "ds"):
-                hit("D", 5, {x for x in sg if x[0] == "s"} & r)
-            states += (int(ops2[0], 0) + 1) if op2 == "s_nop" and ops2 else 1
-            if op2.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
-                break                                   # (what precedes a branch on the taken path is not in address order)
-    # S: path-sensitive walk from every scalar load to the first full lgkmcnt wait
-    index = {a: i for i, (a, *_rest) in enumerate(ins)}
+def waitcnt(txt):
+    """'s_waitcnt vmcnt(0) lgkmcnt(1)' -> {'vmcnt': 0, 'lgkmcnt': 1}; a counter that is not named is not waited for"""
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"(vmcnt|lgkmcnt|expcnt)\((\d+)\)", txt)}
 
-    def target(i):                                       # SOPP branch: target = address + 4 + 4 * simm16 (the low half of the instruction word)
-        a, word = raw[i].split("//")[1].split(":")
+
+class Program:
+    def __init__(self, path):
+        text = subprocess.check_output([OBJDUMP, "-d", path], text=True)
+        self.ins, self.raw = [], []
+        for l in text.splitlines():
+            if "//" not in l or not l.startswith("\t"):
+                continue
+            addr = l.split("//")[1].split(":")[0].strip()
+            p = parse(l)
+            if p:
+                self.ins.append((addr, l.split("//")[0].strip(), *p)); self.raw.append(l)
+        self.index = {a: i for i, (a, *_r) in enumerate(self.ins)}
+        self.cls = [classify(op, ops) for (_a, _t, op, ops) in self.ins]
+        n = len(self.ins)
+        self.succ = [[] for _ in range(n)]
+        self.pred = [[] for _ in range(n)]
+        self.unresolved = []                                # branches whose target is not an instruction of this object
+        for i, (addr, txt, op, ops) in enumerate(self.ins):
+            nxt = []
+            if op.startswith("s_endpgm"):
+                pass
+            elif op.startswith("s_branch"):
+                t = self.target(i)
+                if t is None:
+                    self.unresolved.append(i)
+                else:
+                    nxt.append(t)
+            elif op.startswith("s_cbranch"):
+                t = self.target(i)
+                if t is None:
+                    self.unresolved.append(i)
+                else:
+                    nxt.append(t)
+                if i + 1 < n:
+                    nxt.append(i + 1)
+            elif op.startswith(("s_setpc", "s_swappc")):
+                self.unresolved.append(i)
+            elif i + 1 < n:
+                nxt.append(i + 1)
+            for t in nxt:
+                if t not in self.succ[i]:
+                    self.succ[i].append(t); self.pred[t].append(i)
+
+    def target(self, i):                                    # SOPP branch: target = address + 4 + 4 * simm16 (the low half of the instruction word)
+        a, word = self.raw[i].split("//")[1].split(":")
         simm = int(word.split()[0], 16) & 0xffff
         simm -= 0x10000 if simm & 0x8000 else 0
-        return index.get("%012X" % (int(a.strip(), 16) + 4 + 4 * simm))
+        return self.index.get("%012X" % (int(a.strip(), 16) + 4 + 4 * simm))
 
+    def states_of(self, j):                                 # wait states instruction j provides to what follows it
+        _a, _t, op, ops = self.ins[j]
+        return (int(ops[0], 0) + 1) if op == "s_nop" and ops else 1
+
+
+# Findings the scan cannot clear by itself because it does not track exec masks: (rule, producer regex, consumer regex, why it is not a hazard).
+# A waiver is applied only by scan(..., waive=True); what it suppressed is returned beside the findings, and the test pins the exact set.
+WAIVERS = [
+    ("V", r"ds_read_[iu]16 v1, v16", r"v_add_u32_e32 v1, -1, v1",
+     "fused trip: the pop of the node step reads the stack entry into vCur for lanes of s[64:65] (cur >= 0, no child to enter), the triangle step "
+     "that follows advances vCur of lanes of s[66:67] (cur < 0): the two masks are disjoint by construction, LDS returns and VALU writes are per "
+     "lane, and POP_FINISH waits lgkmcnt(0) before any lane of either mask reads vCur"),
+]
+
+
+def scan(path, waive=False):
+    """-> (instructions, findings) or, with waive=True, (instructions, findings, waived)"""
+    n, found = _scan(path)
+    if not waive:
+        return n, found
+    kept, waived = [], []
+    for f in found:
+        w = next((k for k, (rule, prod, cons, _why) in enumerate(WAIVERS) if f[0] == rule and re.fullmatch(prod, f[4]) and re.fullmatch(cons, f[6])), None)
+        (waived if w is not None else kept).append(f if w is None else (w, f))
+    return n, kept, waived
+
+
+def _scan(path):
+    P = Program(path)
+    ins = P.ins
+    found = []
+    for i in P.unresolved:
+        found.append(("X", 0, 0, ins[i][0], ins[i][1], ins[i][0], "branch target is not an instruction of this object: the paths behind it were not scanned", []))
+
+    # ---- wait-state rules: look back from every instruction along every predecessor path, up to MAX_NEED wait states
+    def pair(rule_hits, i, j, states):
+        addr, txt, op, ops = ins[i]
+        kind, w, r = P.cls[i]
+        a2, t2, op2, ops2 = ins[j]
+        k2, w2, r2 = P.cls[j]
+
+        def hit(rule, need, regs_):
+            if regs_ and states < need:
+                rule_hits.add((rule, need, states, a2, t2, addr, txt, tuple(sorted(regs_))))
+        sg = {x for x in w2 if x[0] == "s" or x.startswith("vcc")} if k2 == "valu" else set()
+        if kind == "valu":
+            lane_sel = op.startswith(("v_readlane", "v_writelane"))
+            if lane_sel and ops:
+                hit("B", 4, sg & regs(ops[-1]))
+            hit("A", 2, sg & r)
+            if op.startswith("v_div_fmas"):
+                hit("C", 4, sg & {"vcc_lo", "vcc_hi"})
+            if op.startswith(("v_readfirstlane", "v_readlane")) and k2 == "valu":
+                hit("E", 1, {x for x in w2 if x[0] == "v"} & r)
+            if k2 == "valu" and op2.startswith(TRANS):
+                hit("F", 1, {x for x in w2 if x[0] == "v"} & r)
+            if k2 in ("vmem", "ds"):
+                hit("G", 1, store_data(op2, ops2) & w)
+            if op.startswith(("v_readfirstlane", "v_readlane", "v_writelane")) and k2 == "valu" and op2.startswith("v_cmpx"):
+                hit("H", 4, {"exec"})
+        if kind in ("vmem", "ds"):
+            hit("D", 5, {x for x in sg if x[0] == "s"} & r)
+
+    hits = set()
+    for i in range(len(ins)):
+        kind = P.cls[i][0]
+        if kind not in ("valu", "vmem", "ds"):
+            continue
+        seen = set()
+        work = [(j, 0) for j in P.pred[i]]
+        while work:
+            j, states = work.pop()
+            if (j, states) in seen or states >= MAX_NEED:
+                continue
+            seen.add((j, states))
+            pair(hits, i, j, states)
+            ns = states + P.states_of(j)
+            for q in P.pred[j]:
+                work.append((q, ns))
+    found += [(*h[:7], list(h[7])) for h in sorted(hits)]
+
+    # ---- S: from every scalar load to the first full lgkmcnt wait on every path
     for i, (addr, txt, op, ops) in enumerate(ins):
-        if not (op.startswith("s_load") or op.startswith("s_memtime") or op.startswith("s_buffer_load")):
+        if P.cls[i][0] != "smem":
             continue
         dest = regs(ops[0])
-        seen, work = set(), [(i + 1, 0)]
+        seen, work = set(), list(P.succ[i])
+        if not P.succ[i]:
+            found.append(("S", 0, 0, addr, txt, addr, "(no successor)", sorted(dest)))
         while work:
-            j, depth = work.pop()
-            while j is not None and j < len(ins) and j not in seen and depth < 400:
-                seen.add(j); depth += 1
-                a2, t2, op2, ops2 = ins[j]
-                if op2 == "s_waitcnt" and ("lgkmcnt(0)" in t2):
-                    break
-                k2, w2, r2 = classify(op2, ops2)
-                if op2.startswith("s_endpgm"):
-                    break                                # (s_endpgm waits for everything outstanding)
-                if (w2 | r2) & dest and not (k2 == "smem" and not (r2 & dest)):
-                    found.append(("S", 0, 0, addr, txt, a2, t2, sorted((w2 | r2) & dest)))
-                    break
-                if op2.startswith("s_branch"):
-                    j = target(j); continue
-                if op2.startswith("s_cbranch"):
-                    tj = target(j)
-                    if tj is not None:
-                        work.append((tj, depth))
-                j += 1
+            j = work.pop()
+            if j in seen:
+                continue
+            seen.add(j)
+            a2, t2, op2, ops2 = ins[j]
+            if op2 == "s_waitcnt" and waitcnt(t2).get("lgkmcnt") == 0:
+                continue
+            if op2.startswith("s_endpgm"):
+                continue                                    # (s_endpgm waits for everything outstanding)
+            k2, w2, r2 = P.cls[j]
+            if (w2 | r2) & dest and not (k2 == "smem" and not (r2 & dest)):
+                found.append(("S", 0, 0, addr, txt, a2, t2, sorted((w2 | r2) & dest)))
+                continue
+            work += P.succ[j]
+
+    # ---- V: from every vector-memory load / LDS read to a wait that covers it, on every path
+    for i, (addr, txt, op, ops) in enumerate(ins):
+        kind, w, _r = P.cls[i]
+        if kind not in ("vmem", "ds") or not w:
+            continue
+        counter = "vmcnt" if kind == "vmem" else "lgkmcnt"
+        dest = {x for x in w if x[0] in "va"}
+        if not dest:
+            continue
+        best = {}                                           # instruction -> smallest k (younger operations of the counter) it has been reached with
+        work = [(j, 0) for j in P.succ[i]]
+        while work:
+            j, k = work.pop()
+            if j in best and best[j] <= k:
+                continue
+            best[j] = k
+            a2, t2, op2, ops2 = ins[j]
+            if op2 == "s_waitcnt":
+                n = waitcnt(t2).get(counter)
+                if n is not None and n <= k:
+                    continue                                # covered on this path
+            if op2.startswith("s_endpgm"):
+                continue
+            k2, w2, r2 = P.cls[j]
+            is_load = k2 in ("vmem", "ds") and bool(w2)
+            touched = (r2 & dest) | (set() if is_load else (w2 & dest))
+            if touched and j != i:
+                found.append(("V", 0, k, addr, txt, a2, t2, sorted(touched)))
+                continue
+            k2n = min(k + 1, 64) if k2 == kind else k       # (every operation of the kind counts: loads, stores, atomics; LDS-DMA is not used here)
+            for q in P.succ[j]:
+                work.append((q, k2n))
     return len(ins), found
 
 
@@ -208,9 +333,12 @@ if __name__ == "__main__":
     paths = sys.argv[1:] or ["build/asm/pt_extend_hsaco/pt_extend_s16.hsaco"]
     bad = 0
     for p in paths:
-        n, found = scan(p)
-        print(f"{p}: {n} instructions, {len(found)} hazard(s)")
+        n, found, waived = scan(p, waive=True)
+        print(f"{p}: {n} instructions, {len(found)} finding(s), {len(waived)} waived (lane-disjoint, see WAIVERS)")
         for rule, need, have, a2, t2, a, t, rg in found:
-            print(f"  {rule}: needs {need} wait state(s), has {have}: {a2}  {t2}   ->   {a}  {t}   [{', '.join(rg)}]")
+            if rule in ("S", "V", "X"):
+                print(f"  {rule}: {a2}  {t2}   ->   {a}  {t}   [{', '.join(rg)}]" + (f"  ({have} younger operation(s) of the counter on this path)" if rule == "V" else ""))
+            else:
+                print(f"  {rule}: needs {need} wait state(s), has {have}: {a2}  {t2}   ->   {a}  {t}   [{', '.join(rg)}]")
         bad += len(found)
     sys.exit(1 if bad else 0)

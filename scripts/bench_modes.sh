@@ -9,6 +9,6 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d.get('roofline',{})
-        print('$cfg mode $mode [$FL] ->', d['value'], 'Ms/s  ms/step', d['ms_per_step'], ('  extend avg %s  shade avg %s' % (r.get('in_run',{}).get('avg_launch_ms'), r.get('shade',{}).get('in_run',{}).get('avg_launch_ms'))) if r else '')
+        print('$cfg mode $mode [$FL] ->', d['value'], 'Ms/s  ms/step', d['ms_per_step'], ('  extend avg %s  shade avg %s' % (r.get('avg_launch_ms'), r.get('shade',{}).get('avg_launch_ms'))) if r else '')
 "
 done; done; done

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/<tag>/trace_stats.txt (per-kernel calls / average duration + the bench line's own
-# HIP-event figures: the average pt_extend_asm duration must agree with roofline.in_run.avg_launch_ms).  --no-alone-pass: without it the trace also
+# HIP-event figures: the average pt_extend_asm duration must agree with roofline.avg_launch_ms).  --no-alone-pass: without it the trace also
 # holds the shorter launches of the one-stream pass that follows the timed region.      usage: scripts/trace_stats.sh <out-tag> [bench flags]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-trace}; shift
@@ -19,8 +19,8 @@ for f in glob.glob(O + "/trace/**/*kernel_stats.csv", recursive=True):
 for l in open(O + "/bench_trace.json"):
     if l.startswith("{"):
         d = json.loads(l)
-        print("bench line of the traced run:", json.dumps({k: d[k] for k in ("value", "ms_per_step", "steps")}), json.dumps({k: d["roofline"]["in_run"][k] for k in ("avg_launch_ms", "launches", "frac")}),
-              "shade avg", d["roofline"]["shade"]["in_run"]["avg_launch_ms"])
+        print("bench line of the traced run:", json.dumps({k: d[k] for k in ("value", "ms_per_step", "steps")}), json.dumps({k: d["roofline"][k] for k in ("avg_launch_ms", "launches", "frac")}),
+              "shade avg", d["roofline"]["shade"]["avg_launch_ms"])
 PY
 rm -rf $O/trace
 cat $O/trace_stats.txt

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -148,6 +149,33 @@ def test_jni_shim_covers_the_boundary():
                  "pt_next_image", "pt_finish_image", "pt_image_device", "pt_gather_image", "pt_synchronize", "pt_read_frame", "pt_read_display", "pt_get_counters",
                  "pt_reset_counters", "pt_last_error"):
         assert need in called, need
+
+
+def test_jni_shim_type_checks():
+    """N1 as far as a box without a JDK allows: pt_jni.c compiled (-fsyntax-only -Wall -Wextra -Werror) against tests/c/jni_standin/jni.h, a
+    hand-written stand-in that declares the JNI types and the eleven JNIEnv functions the shim calls with the prototypes of the JNI
+    specification, and every Java_Main_PtNative_* definition compared with the `native` declaration of PtNative.java it implements (return
+    type and every parameter type, in order).  This pins nothing about a real JVM — nothing is linked or run, and the stand-in is the
+    builder's reading of the specification; it proves that the file is valid C, that its calls match those prototypes and that the two
+    sides of the JNI boundary agree.  N1 itself (the reference's Main driving the library) stays open: no JDK here or on the GPU boxes."""
+    jdir = os.path.join(ROOT, "pathtracer-0_amd", "java")
+    cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I" + os.path.join(ROOT, "tests", "c", "jni_standin"),
+           "-I" + os.path.join(ROOT, "include"), os.path.join(jdir, "pt_jni.c")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    java = open(os.path.join(jdir, "Main", "PtNative.java")).read()
+    jni = open(os.path.join(jdir, "pt_jni.c")).read()
+    jtype = {"int": "jint", "long": "jlong", "boolean": "jboolean", "void": "void", "int[]": "jintArray", "long[]": "jlongArray", "Buffer": "jobject", "String": "jstring"}
+    decl = {m.group(2): (m.group(1), [a.split()[0] for a in m.group(3).split(",") if a.strip()])
+            for m in re.finditer(r"public static native ([\w\[\]]+) (\w+)\(([^)]*)\)", java)}
+    defs = {m.group(2): (m.group(1), [a.rsplit(None, 1)[0].strip() for a in m.group(3).split(",")])
+            for m in re.finditer(r"JNIEXPORT (\w+) JNICALL Java_Main_PtNative_(\w+)\(([^)]*)\)", jni)}
+    assert set(decl) == set(defs) and len(decl) >= 21
+    for name, (ret, args) in decl.items():
+        cret, cargs = defs[name]
+        assert cret == jtype[ret], (name, cret, ret)
+        assert cargs[:2] == ["JNIEnv*", "jclass"], (name, cargs[:2])          # static native methods: (JNIEnv*, jclass, ...)
+        assert cargs[2:] == [jtype[a] for a in args], (name, cargs[2:], args)
 
 
 def test_c_client_names_every_boundary_symbol():

@@ -41,6 +41,30 @@ def _assemble(tmp_path, body):
     # a scalar load still in flight when a branch leaves for code that reuses its registers (the round-3 refill bug: root boxes into s[64:71], the trip's masks)
     ("  s_load_dwordx2 s[4:5], s[0:1], 0x0\n  s_cbranch_execz skip\n  s_waitcnt lgkmcnt(0)\n  s_mov_b32 s6, s4\nskip:\n  s_mov_b64 s[4:5], exec", {"S"}),
     ("  s_load_dwordx2 s[4:5], s[0:1], 0x0\n  s_waitcnt lgkmcnt(0)\n  s_cbranch_execz skip\n  s_mov_b32 s6, s4\nskip:\n  s_mov_b64 s[4:5], exec", set()),
+    # the same hazards across a TAKEN branch and across a loop back-edge (look-back runs over every predecessor of a label)
+    ("  v_cmp_lt_f32_e32 vcc, v1, v2\n  s_cbranch_scc1 L\n  s_nop 3\nL:\n  v_cndmask_b32_e32 v3, v4, v5, vcc", {"A"}),
+    ("  v_cmp_lt_f32_e32 vcc, v1, v2\n  s_nop 0\n  s_cbranch_scc1 L\n  s_nop 3\nL:\n  v_cndmask_b32_e32 v3, v4, v5, vcc", set()),
+    ("L:\n  v_cndmask_b32_e32 v3, v4, v5, vcc\n  s_nop 3\n  v_cmp_lt_f32_e32 vcc, v1, v2\n  s_cbranch_scc1 L", {"A"}),
+    ("  v_mov_b32_e32 v1, v2\n  s_branch L\n  s_nop 0\nL:\n  v_readfirstlane_b32 s4, v1", set()),                 # the branch itself is a wait state
+    ("  v_readfirstlane_b32 s4, v1\n  s_cbranch_scc0 L\n  s_nop 4\nL:\n  global_load_dword v2, v3, s[4:5]\n  s_waitcnt vmcnt(0)", {"D"}),
+    # a scalar load whose registers are reused 450 instructions later without a wait (no depth limit on the walk)
+    ("  s_load_dwordx2 s[4:5], s[0:1], 0x0\n" + "  s_nop 0\n" * 450 + "  s_mov_b32 s6, s4", {"S"}),
+    # V: vector-memory loads / LDS reads whose destination is touched before a wait that covers it
+    ("  global_load_dword v1, v2, s[4:5]\n  v_mov_b32_e32 v3, v1\n  s_waitcnt vmcnt(0)", {"V"}),
+    ("  global_load_dword v1, v2, s[4:5]\n  v_mov_b32_e32 v1, 0\n  s_waitcnt vmcnt(0)", {"V"}),                         # written, not read: the data lands on top
+    ("  global_load_dword v1, v2, s[4:5]\n  global_load_dword v5, v2, s[4:5] offset:4\n  s_waitcnt vmcnt(1)\n  v_mov_b32_e32 v3, v1\n  s_waitcnt vmcnt(0)", set()),
+    ("  global_load_dword v1, v2, s[4:5]\n  global_load_dword v5, v2, s[4:5] offset:4\n  s_waitcnt vmcnt(1)\n  v_mov_b32_e32 v3, v5\n  s_waitcnt vmcnt(0)", {"V"}),
+    ("  ds_read_b32 v1, v2\n  s_waitcnt vmcnt(0)\n  v_mov_b32_e32 v3, v1\n  s_waitcnt lgkmcnt(0)", {"V"}),               # the wrong counter
+    ("  ds_read_b32 v1, v2\n  ds_write_b32 v2, v6\n  s_waitcnt lgkmcnt(1)\n  v_mov_b32_e32 v3, v1\n  s_waitcnt lgkmcnt(0)", set()),   # LDS operations return in order
+    # a load left in flight across the back-edge and used at the top of the loop before the wait (the fetch-at-decision pattern gone wrong)
+    ("L:\n  v_add_u32_e32 v3, v1, v1\n  s_waitcnt vmcnt(0)\n  global_load_dword v1, v2, s[4:5]\n  s_cbranch_scc1 L\n  s_waitcnt vmcnt(0)", {"V"}),
+    ("L:\n  s_waitcnt vmcnt(0)\n  v_add_u32_e32 v3, v1, v1\n  global_load_dword v1, v2, s[4:5]\n  s_cbranch_scc1 L\n  s_waitcnt vmcnt(0)", set()),
+    # one path of two waits, the other does not
+    ("  global_load_dword v1, v2, s[4:5]\n  s_cbranch_scc1 L\n  s_waitcnt vmcnt(0)\nL:\n  v_mov_b32_e32 v3, v1\n  s_waitcnt vmcnt(0)", {"V"}),
+    # the two arms of a fetch: disjoint lanes of the same registers from two counters, one wait for both (the kernel's NODE_LDS / NODE_GLB)
+    ("  ds_read_b32 v1, v2\n  global_load_dword v1, v3, s[4:5]\n  s_waitcnt vmcnt(0) lgkmcnt(0)\n  v_mov_b32_e32 v4, v1", set()),
+    # a path the scan cannot follow is a finding, not a silent pass
+    ("  s_getpc_b64 s[4:5]\n  s_setpc_b64 s[4:5]", {"X"}),
 ])
 def test_checker_finds_what_it_is_meant_to(tmp_path, body, rules):
     _, found = _checker().scan(_assemble(tmp_path, body))
@@ -55,5 +79,8 @@ def test_product_code_objects_are_hazard_free(pt):
     objs = sorted(f for f in os.listdir(d) if f.endswith(".hsaco"))
     assert len(objs) == 8
     for f in objs:
-        n, found = _checker().scan(os.path.join(d, f))
+        n, found, waived = _checker().scan(os.path.join(d, f), waive=True)
         assert n > 1000 and not found, (f, found[:5])
+        # the one pattern the lane-agnostic scan cannot clear (asm_hazards.WAIVERS[0]: the node step's pop and the triangle step's advance of
+        # vCur work on disjoint lane masks): exactly its two instances (FUSED_TRIP 0 and FUSED_TRIP 1), nothing else rides on a waiver
+        assert [w for w, _ in waived] == [0, 0], (f, waived)

@@ -62,8 +62,14 @@ def test_hip_reproduces_golden(renderer_mod, path):
     r.reset_frame(); r.reset_counters()
     r.render_batch(1, z["seeds"])
     got = r.read_frame(); cnt = r.counters()
+    # ... and once more on the shipped kernels (no statistics: the hand-written intersect kernel where the scene is one it takes)
+    r.set_option("count_stats", 0)
+    r.reset_frame()
+    r.render_batch(1, z["seeds"])
+    shipped = r.read_frame()
     r.close()
     assert _same(got, z["frame"])
+    assert _same(shipped, z["frame"])
     ref = dict(zip(["segments", "nodes", "tritests", "hitupd", "samples", "boxtests"], [int(v) for v in z["counters"][:6]]))
     for k, v in ref.items():
         assert cnt[k] == v, (k, cnt[k], v)

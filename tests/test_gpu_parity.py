@@ -29,6 +29,15 @@ def render_both(pt, oracle, renderer_mod, wl, n_frames, first=1, count_stats=Tru
     r.render_batch(first, seeds)
     got = r.read_frame()
     cnt = r.counters()
+    if count_stats:
+        # the statistics pass runs the counting variants (the compiled intersect kernel, k_shade<STATS>); the SHIPPED kernels — the hand-written
+        # intersect kernel wherever the scene is one it takes — render the same frames again in the same context and must give the same bits
+        r.set_option("count_stats", 0)
+        r.reset_frame()
+        r.render_batch(first, seeds)
+        shipped = r.read_frame()
+        same = (shipped == got) | (np.isnan(shipped) & np.isnan(got))
+        assert same.all(), f"shipped kernels differ from the counting variants in {int((~same).sum())} floats"
     r.close()
     sc = oracle.Scene.from_workload(wl)
     ref, ocnt = oracle.render_frames(sc, W, H, first, n_frames, seeds, nthreads=8)
@@ -447,6 +456,99 @@ def test_sky_texture_bilinear_repeat(pt, oracle, renderer_mod):
     wl.sky = rs.randint(0, 256, size=(5, 7, 4)).astype(np.uint8)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2)
     assert_same(got, ref, cnt, ocnt)
+
+
+def _gradient_sky(h, w, seed=9):
+    """a non-trivial equirect sky: smooth gradients + seeded noise + a small "sun", every texel different from its neighbours"""
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.float64)
+    img[..., 0] = 90 + 80 * np.sin(2 * np.pi * x / w) + 40 * y / h
+    img[..., 1] = 110 + 60 * np.cos(4 * np.pi * x / w) * (1 - y / h)
+    img[..., 2] = 200 - 120 * y / h
+    img[..., :3] += rs.uniform(-12, 12, size=(h, w, 3))
+    sun = (x - 0.3 * w) ** 2 + (y - 0.25 * h) ** 2 < (0.02 * w) ** 2
+    img[sun, :3] = 255
+    img[..., 3] = 255
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_full_size_c3_with_equirect_sky(pt, oracle, renderer_mod):
+    """the reference binds an equirect image as texture 0 (dispatch.java:221) and reads it on every miss (frag.glsl:235-242, :877): full C3
+    size with a 1024x512 sky and an open room (no ceiling light needed: the sky is the light), on the shipped kernels, against the oracle on
+    a pixel lattice"""
+    W, H = 1920, 1080
+    wl = pt.scenes.build("C3", W, H)
+    wl.sky = _gradient_sky(512, 1024)
+    b = dict(wl.buffers)
+    b[0] = np.array([0.0, 1.0, -2.6], np.float32)        # further back: a third of the primary rays pass the room and see the sky directly
+    wl = pt.scenes.Workload(wl.name, W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    seeds = seeds_for(pt, 1, 2)
+    r = renderer_mod.Renderer(W, H, devices=[0, 0])      # the production form: two streams on the GPU
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch(1, seeds)
+    a = r.read_frame().copy()
+    r.close()
+    sc = oracle.Scene.from_workload(wl)
+    ref = np.zeros((H, W, 4), np.float32)
+    for i, sd in enumerate(seeds):
+        oracle.render(sc, W, H, 1 + i, sd, ref, nthreads=8, xs=24, ys=27)
+    assert np.array_equal(a[::27, ::24], ref[::27, ::24])
+    lattice = a[::27, ::24, :3] / 2.0
+    assert len(np.unique(np.round(lattice.reshape(-1, 3), 4), axis=0)) > 1000      # the sky really varies over the image
+    # and the small-size form through the counting kernels too
+    small = pt.scenes.Workload(wl.name, 96, 54, dict(b, **{4: pt.scenes.make_params(96, 54, wl.sample_res, wl.max_bounces)}), wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, small, 2)
+    assert_same(got, ref, cnt, ocnt)
+
+
+NO_VN_CUBE = """v -1 -1 -1\nv 1 -1 -1\nv 1 1 -1\nv -1 1 -1\nv -1 -1 1\nv 1 -1 1\nv 1 1 1\nv -1 1 1
+f 1 2 3\nf 1 3 4\nf 5 7 6\nf 5 8 7\nf 1 5 6\nf 1 6 2\nf 4 3 7\nf 4 7 8\nf 1 4 8\nf 1 8 5\nf 2 6 7\nf 2 7 3\n"""
+
+
+def _no_vn_workload(pt, W, H):
+    """the shape of the reference's only shipped asset (src/objs/table - Copy.obj: five `o` cubes, `v` and `f a b c` lines only — no vn, vt or
+    usemtl) plus two scene.addTri triangles (dispatch.java:1013-1015): every such triangle gets normalize(vec(0)) = NaN normals
+    (dispatch.java:901-902, 1241-1243), uploaded as they are.  (addTri only appends to the triangle list: such a triangle is
+    in no BVH and no ray ever meets it, in the reference as here; the cubes are what the paths hit.)  Text generated here, not the reference's file."""
+    S = pt.scenes
+    sc = S._new_scene()
+    sc.addMaterial("default"); sc.setLastMtl("Kd", (0.8, 0.8, 0.8)); sc.setLastMtl("Pr", 1)
+    sc.addMaterial("glassy"); sc.setLastMtl("Tr", 0.8); sc.setLastMtl("Ni", 1.4); sc.setLastMtl("Pr", 1)
+    lines, base = [], 0
+    for k, (cx, cy, cz, h) in enumerate([(0.0, 0.5, 3.0, 0.5), (1.4, 0.3, 2.6, 0.3), (-1.3, 0.35, 2.4, 0.35), (0.6, 0.2, 1.7, 0.2), (-0.5, 1.4, 3.4, 0.25)]):
+        lines.append(f"o cube{k}")
+        for ln in NO_VN_CUBE.replace("\\n", "\n").splitlines():
+            t = ln.split()
+            if t[0] == "v":
+                lines.append("v %.9g %.9g %.9g" % (cx + h * float(t[1]), cy + h * float(t[2]), cz + h * float(t[3])))
+            else:
+                lines.append("f %d %d %d" % tuple(int(q) + base for q in t[1:]))
+        base += 8
+    sc.addObjectText("\n".join(lines) + "\n", 0, parentDirectory="")
+    # a ground quad WITH normals, so that finite and NaN pixels sit side by side
+    o = S.Obj(); o.group("ground"); o.quad((-6, 0, -2), (6, 0, -2), (6, 0, 10), (-6, 0, 10), (0, 1, 0))
+    sc.addObjectText(o.text(), 0, parentDirectory="")
+    sc.addTri((-2.5, 0.1, 4.0), (-1.5, 0.1, 4.0), (-2.0, 1.6, 4.2), 0)
+    sc.addTri((1.8, 0.1, 3.8), (2.8, 0.1, 3.8), (2.3, 1.2, 3.6), 1)
+    return S._finish("no_vn", sc, W, H, (0.0, 0.9, -0.5), (0.08, 0.0, 0.0), (153, 179, 230), 4, 6)
+
+
+def test_no_vn_geometry_renders_nan_like_the_oracle(pt, oracle, renderer_mod):
+    """Q-5: OBJ groups without `vn` and scene.addTri triangles carry NaN normals; a path that hits one continues along a NaN direction
+    (misses everything, samples the sky at NaN coordinates) and its pixel is NaN in the reference.  NaN == NaN against the oracle, on the
+    counting and on the shipped kernels, one stream and two."""
+    wl = _no_vn_workload(pt, 96, 54)
+    tri = wl.buffers[3].reshape(-1, 40)
+    assert np.isnan(tri[:60, 12:15]).all() and np.isnan(tri[-2:, 12:15]).all() and np.isfinite(tri[60:62, 12:15]).all()
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
+    assert_same(got, ref, cnt, ocnt)
+    nan_px = np.isnan(ref[..., :3]).any(axis=2)
+    assert 0.05 < nan_px.mean() < 0.9, nan_px.mean()          # cubes and triangles are NaN, ground and sky are not
+    r = renderer_mod.Renderer(wl.W, wl.H, devices=[0, 0])
+    r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds_for(pt, 1, 3))
+    two = r.read_frame(); r.close()
+    assert_same(two, ref)
 
 
 def test_rotated_camera_and_rotated_ellipsoid(pt, oracle, renderer_mod):
