@@ -28,6 +28,10 @@ extern "C" {
  *      branches as written, the continuous functions (Box-Muller's log / cos / sqrt, normalize, 1/d, 1/det, the BSDF weights' divides) on the
  *      hardware's v_log / v_cos / v_sqrt / v_rsq / v_rcp units: results within north_star's per-pixel RMSE <= 1e-3 of the oracle, not bit-identical.
  *      Applies to path tracing (RAYTRACING == 1) without statistics; takes effect with the next frame stream.
+ * 18 = index-stack encoding of the path state (tests): 1 forces 8-bit dictionary codes (a 16-B state group) where the scene's refraction indices would
+ *      fit the 3-bit codes that ride beside the throughput; 0 (default) automatic.
+ * 19 = node records of the hand-written intersect kernel: -1 automatic (default: 80-B records whose plane pairs are stored in direction-sign order while the
+ *      inner nodes fit the caches, 64-B records with the min/max step for larger trees), 0 80-B, 1 64-B.
  * Queries (tests): 12 = PT_OK iff the current scene runs on the hand-written intersect kernel (else PT_ERR_UNSUPPORTED and the reason in pt_last_error),
  * 13 = PT_OK iff that kernel has been launched more than `value` times by this context. */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
@@ -46,7 +50,8 @@ int pt_kernel_time_median(pt_ctx* ctx, int kernel, double* median_ms);
 
 /* Debug / parity probes (used by tests): evaluates the device numeric contract.
  * fn: 0 sin, 1 cos, 2 log, 3 exp, 4 atan(x,y), 5 asin; 6 / 7 / 8 = the state after / the result of / random() of ONE NextRandom call
- * (frag.glsl:686-694), the uint32 state passed as float bits; host pointers, n elements. */
+ * (frag.glsl:686-694), the uint32 state passed as float bits; 9 = byte / 255.0f as the texture samplers evaluate it (x = the byte as a float);
+ * host pointers, n elements. */
 int pt_debug_math(pt_ctx* ctx, int fn, const float* x, const float* y, float* out, size_t n);
 /* Single rays through the intersect kernel option 4 selects (the production kernels included): o,d are n*3 f32 (host); out is n*4 f32 (t,u,v) + prim as int bits */
 int pt_debug_intersect(pt_ctx* ctx, const float* o, const float* d, float* out, size_t n);

@@ -42,8 +42,9 @@ struct MatRec {                                                                 
     float Ka[3], ssColor[3], ssRadius[3];                                        // only directDiffuse (frag.glsl:661-675)
     int hasMaps;                                                                 // any of the map_* below > -1
     int map_Ka, map_Kd, map_Ks, map_Ke, map_Tr, map_Pm, map_Pr, map_Pc, map_norm; // texture indices (mapMtl :210-225, :827); -1 = none
-};                                                                               // 40 dwords = 160 B
-struct TexRec { const float4* data; int w, h; };                                 // one entry of the bindless table (binding 15), RGBA32F texels
+    int niCode;                                                                  // Ni as an entry of the scene's refraction-index dictionary (DevScene::ni8 / niTable)
+};                                                                               // 41 dwords = 164 B
+struct TexRec { const uchar4* data; int w, h; };                                 // one entry of the bindless table (binding 15), RGBA8 texels as uploaded
 
 struct FrameConst {            // uniform per batch; written by k_frame_setup
     float screenSize, focalLength, resolution, screenHratio, SAMPLE_RES, MAX_BOUNCES, BLUR, FOCAL_DISTANCE, AUTO_FOCUS;
@@ -61,9 +62,14 @@ struct DevScene {
     const ObjRoot* roots; int numObj;
     const EllipRec* ellip; int numEllip;
     const MatRec* mats;   int numMat;
-    const float4* sky;    int skyW, skyH;   // texture 0 as RGBA32F: texel = byte / 255.0f (the same binary32 division, done once at upload)
+    const uchar4* sky;    int skyW, skyH;   // texture 0 as the RGBA8 texels that were uploaded (dispatch.java:349-354); unorm8() at fetch
     const TexRec* tex;    int numTex;       // the whole texture table (entry 0 = sky again)
     int ldsNodes, ldsTris;                   // how many leading node / triangle records the intersect kernel stages in LDS
+    // The refraction-index stack (frag.glsl:136-158) only ever holds 0.0 (an untouched slot), 1.0029 (:816) and the Ni of a material (:834): the path
+    // state carries its ten slots as CODES into this dictionary — 3 bits each when the scene has at most 8 distinct values (one dword beside the
+    // throughput), 8 bits each otherwise (a 16-B group) — instead of ten floats.  Codes 0 and 1 are 0.0f and 1.0029f.
+    float ni8[8];                            // the dictionary of a 3-bit scene (kernel arguments: scalar registers)
+    const float* niTable;                    // the dictionary in memory (8-bit scenes)
 };
 
 struct Counters { unsigned nodes = 0, tritests = 0, hitupd = 0, boxtests = 0; };
@@ -288,9 +294,12 @@ PM_DEV vec3 randLambertianDistVec(uint32_t& st) {
 // ------------------------------------------------------------------------------------------------
 // Path state of one lane (registers); stored SoA in groups of float4 (see pt_hip.hip)
 // ------------------------------------------------------------------------------------------------
-// flags word of a path slot (G1.w): bits 0-11 bounce, 12-23 sample (the loop counters of frag.glsl:820 / :898; their bounds are
-// floats in the shader, here up to 4095), 24-27 size of the refraction-index stack (0..10), then the booleans
-constexpr uint32_t FL_COUNT_MASK = 0xfffu; constexpr int FL_SAMPLE_SHIFT = 12, FL_STACK_SHIFT = 24;
+// flags word of a path slot (G1.w): bits 0-11 bounce, 12-22 sample (the loop counters of frag.glsl:820 / :898; their bounds are
+// floats in the shader, here up to 4095 / 2047), 23 FL_INCNZ, 24-27 size of the refraction-index stack (0..10), then the booleans
+constexpr uint32_t FL_COUNT_MASK = 0xfffu, FL_SAMPLE_MASK = 0x7ffu; constexpr int FL_SAMPLE_SHIFT = 12, FL_STACK_SHIFT = 24;
+// bit 23: incLight of the running sample is not +0.0 in every component, i.e. the group G3 holds it (k_shade reads and writes G3 for such lanes only:
+// incLight leaves zero only at an emitter hit that does not end the sample, frag.glsl:865); the sample counter keeps bits 12-22 (SAMPLE_RES <= 2047)
+constexpr uint32_t FL_INCNZ = 1u << 23;
 constexpr uint32_t FL_INOBJ = 1u << 28, FL_APPLYABS = 1u << 29, FL_PROBE = 1u << 30, FL_ALIVE = 1u << 31;
 // directDiffuse's thickness probe (frag.glsl:668): the ray starts ON the hit point (no 1e-4 offset) and traverses only the BVH
 // of the object that was hit.  Probes exist in the RAYTRACING == 0 mode only, where the bounce counter and the index stack are
@@ -307,41 +316,86 @@ struct Path {
     int bounce, sample, stackSize;
     bool inObj, applyAbs, alive, probe; int probeObj;
     vec3 enter; float dist;   // RAY_ENTER_LOCATION, DISTANCE_TRAVELED
-    float s[10];           // refractionIndiceStack
+    uint32_t sc0, sc1, sc2; // refractionIndiceStack as dictionary codes, slot 0 in the lowest bits: 3-bit codes all in sc0; 8-bit codes: slots 0-3, 4-7, 8-9
+    bool incNZ;            // FL_INCNZ
     bool g5loaded, g5dirty; // lazily fetched / modified (enter, dist) group, see k_shade
 };
 
 PM_DEV uint32_t packFlags(const Path& p) {
     const uint32_t lo = p.probe ? ((uint32_t)p.probeObj & FL_COUNT_MASK) : (uint32_t)p.bounce, st = p.probe ? ((uint32_t)p.probeObj >> 12) : (uint32_t)p.stackSize;
-    return lo | ((uint32_t)p.sample << FL_SAMPLE_SHIFT) | (st << FL_STACK_SHIFT) | (p.inObj ? FL_INOBJ : 0u) |
+    return lo | ((uint32_t)p.sample << FL_SAMPLE_SHIFT) | (p.incNZ ? FL_INCNZ : 0u) | (st << FL_STACK_SHIFT) | (p.inObj ? FL_INOBJ : 0u) |
            (p.applyAbs ? FL_APPLYABS : 0u) | (p.alive ? FL_ALIVE : 0u) | (p.probe ? FL_PROBE : 0u);
 }
 PM_DEV void unpackFlags(Path& p, uint32_t f) {
-    p.bounce = f & FL_COUNT_MASK; p.sample = (f >> FL_SAMPLE_SHIFT) & FL_COUNT_MASK; p.stackSize = (f >> FL_STACK_SHIFT) & 0xf;
+    p.bounce = f & FL_COUNT_MASK; p.sample = (f >> FL_SAMPLE_SHIFT) & FL_SAMPLE_MASK; p.stackSize = (f >> FL_STACK_SHIFT) & 0xf; p.incNZ = f & FL_INCNZ;
     p.inObj = f & FL_INOBJ; p.applyAbs = f & FL_APPLYABS; p.alive = f & FL_ALIVE;
     p.probe = f & FL_PROBE; p.probeObj = p.probe ? probeObjOf(f) : 0;
 }
 
-// index stack, frag.glsl:139-158, as a shift array with static indices (stale slots stay readable)
-PM_DEV void addToIndiceStack(Path& p, float e) {
+// index stack, frag.glsl:139-158.  The shader's array shifts move slots [0, size] up (addToIndiceStack, only when size < 10) or slots [1, size) down
+// (removeFirstOfIndiceStack) and leave every other slot as it was — stale values stay readable, and are read (:835, :839 with size 1).  On the packed
+// codes that is one shift of the whole word merged under a mask of the slots the loop touches.  STK: 3 or 8 bits per code.
+template <int STK> PM_DEV void addToIndiceStack(Path& p, uint32_t e) {
     if (p.stackSize < 10) {
-#pragma unroll
-        for (int i = 9; i > 0; i--) if (i <= p.stackSize) p.s[i] = p.s[i - 1];
-        p.s[0] = e;
+        const int n = p.stackSize + 1;                           // slots 0 .. size are rewritten
+        if (STK == 3) {
+            const uint32_t m = n >= 10 ? 0x3fffffffu : ((1u << (3 * n)) - 1u);
+            p.sc0 = ((((p.sc0 << 3) | e) & m) | (p.sc0 & ~m));
+        } else {
+            const unsigned long long lo = (unsigned long long)p.sc0 | ((unsigned long long)p.sc1 << 32);
+            const uint32_t hi = p.sc2;
+            const unsigned long long slo = (lo << 8) | e; const uint32_t shi = ((hi << 8) | (uint32_t)(lo >> 56)) & 0xffffu;
+            const unsigned long long mlo = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull); const uint32_t mhi = n <= 8 ? 0u : ((1u << (8 * (n - 8))) - 1u);
+            const unsigned long long nlo = (slo & mlo) | (lo & ~mlo);
+            p.sc0 = (uint32_t)nlo; p.sc1 = (uint32_t)(nlo >> 32); p.sc2 = (shi & mhi) | (hi & ~mhi);
+        }
         p.stackSize++;
     }
 }
-PM_DEV void removeFirstOfIndiceStack(Path& p) {
+template <int STK> PM_DEV void removeFirstOfIndiceStack(Path& p) {
     if (p.stackSize > 0) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) if (i < p.stackSize - 1) p.s[i] = p.s[i + 1];
+        const int n = p.stackSize - 1;                           // slots 0 .. size-2 are rewritten
+        if (STK == 3) {
+            const uint32_t m = (1u << (3 * n)) - 1u;
+            p.sc0 = ((p.sc0 >> 3) & m) | (p.sc0 & ~m);
+        } else {
+            const unsigned long long lo = (unsigned long long)p.sc0 | ((unsigned long long)p.sc1 << 32);
+            const uint32_t hi = p.sc2;
+            const unsigned long long slo = (lo >> 8) | ((unsigned long long)(hi & 0xffu) << 56); const uint32_t shi = hi >> 8;
+            const unsigned long long mlo = n >= 8 ? ~0ull : ((1ull << (8 * n)) - 1ull); const uint32_t mhi = n <= 8 ? 0u : ((1u << (8 * (n - 8))) - 1u);
+            const unsigned long long nlo = (slo & mlo) | (lo & ~mlo);
+            p.sc0 = (uint32_t)nlo; p.sc1 = (uint32_t)(nlo >> 32); p.sc2 = (shi & mhi) | (hi & ~mhi);
+        }
         p.stackSize--;
     }
+}
+// refractionIndiceStack[slot] for slot 0 or 1 (the only slots trace() reads, :835-839)
+template <int STK> PM_DEV float indiceStackSlot(const DevScene& sc, const Path& p, int slot) {
+    if (STK == 3) {
+        const uint32_t c = (p.sc0 >> (3 * slot)) & 7u;
+        float v = sc.ni8[0];
+#pragma unroll
+        for (uint32_t k = 1; k < 8; k++) v = (c == k) ? sc.ni8[k] : v;           // seven selects on scalar operands, no memory
+        return v;
+    }
+    return sc.niTable[(p.sc0 >> (8 * slot)) & 0xffu];
 }
 
 // texture(textures[0], uv): GL 4.6 §8.14 LINEAR/REPEAT on RGBA8 (dispatch.java:349-354)
 PM_DEV int imod(int a, int n) { int r = a % n; return r < 0 ? r + n : r; }
-PM_DEV vec3 sampleTex(const float4* tex, int w, int h, float u, float v) {
+// byte / 255.0f, the UNORM8 -> float conversion of a GL_RGBA8 texel, correctly rounded without a division: one Newton step on the product with the
+// rounded reciprocal.  Bit-equal to the IEEE quotient for all 256 bytes (tests/test_oracle_kat.py::test_unorm8_reciprocal_form, and on the device
+// pt_debug_math fn 9); the oracle divides.
+PM_DEV float unorm8(uint32_t b) {
+    const float fb = (float)b, r = 0x1.010102p-8f;               // RN(1 / 255)
+    const float q = fb * r;
+    return fmaf(fmaf(-255.0f, q, fb), r, q);
+}
+PM_DEV float4 texel(const uchar4* tex, int idx) {
+    const uchar4 t = tex[idx];
+    return make_float4(unorm8(t.x), unorm8(t.y), unorm8(t.z), unorm8(t.w));
+}
+PM_DEV vec3 sampleTex(const uchar4* tex, int w, int h, float u, float v) {
     float fu = u * (float)w - 0.5f, fv = v * (float)h - 0.5f;
     float flu = (__builtin_fabsf(fu) < 1.0e9f) ? __builtin_floorf(fu) : 0.0f;
     float flv = (__builtin_fabsf(fv) < 1.0e9f) ? __builtin_floorf(fv) : 0.0f;
@@ -349,7 +403,7 @@ PM_DEV vec3 sampleTex(const float4* tex, int w, int h, float u, float v) {
     int i0 = imod((int)flu, w), j0 = imod((int)flv, h);
     int i1 = imod(i0 + 1, w), j1 = imod(j0 + 1, h);
     float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-    float4 p00 = tex[j0 * w + i0], p10 = tex[j0 * w + i1], p01 = tex[j1 * w + i0], p11 = tex[j1 * w + i1];
+    float4 p00 = texel(tex, j0 * w + i0), p10 = texel(tex, j0 * w + i1), p01 = texel(tex, j1 * w + i0), p11 = texel(tex, j1 * w + i1);
     vec3 r;
     r.x = w00 * p00.x + w10 * p10.x + w01 * p01.x + w11 * p11.x;
     r.y = w00 * p00.y + w10 * p10.y + w01 * p01.y + w11 * p11.y;
@@ -464,18 +518,19 @@ PM_DEV void cameraRay(const FrameConst& fc, int W, int H, int px, int py, uint32
     O = origin_jittered;
 }
 // trace() prologue (:811-818): everything a new sample resets that needs no random numbers
-PM_DEV void tracePrologue(Path& p) {
+template <int STK> PM_DEV void tracePrologue(Path& p) {
     p.col = v3(1.0f); p.inc = v3(0.0f);
     p.stackSize = 0;                       // clearIndiceStack
-    addToIndiceStack(p, 1.0029f);
+    if (STK) addToIndiceStack<STK>(p, 1u); // 1.0029 (dictionary code 1); a scene without transmissive materials never reads the stack (:753)
+    else p.stackSize = 1;
     p.inObj = false;
     p.bounce = 0;
     p.probe = false; p.probeObj = 0;
 }
-template <bool FAST = false>
+template <int STK, bool FAST = false>
 PM_DEV void startSample(const FrameConst& fc, int W, int H, int px, int py, Path& p) {
     cameraRay<FAST>(fc, W, H, px, py, p.rng, p.O, p.D);
-    tracePrologue(p);
+    tracePrologue<STK>(p);
 }
 
 // rngState = index + u_seed (:886,:896) for global pixel (px,py); false when the fragment returns early (:887)
@@ -492,8 +547,9 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
 
 // One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
 // Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
-template <bool TRANS, bool TEX, bool FAST = false>
+template <int STK, bool TEX, bool FAST = false>
 PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, const float4* HX, unsigned slot) {
+    constexpr bool TRANS = STK != 0;
     p.bounce++;                                               // :821
     const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
     const vec3 D = p.D;
@@ -527,8 +583,11 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
         ND = dot(N, D);
         N = N * (ND > 0.0f ? -1.0f : 1.0f);                   // :830
         if (TRANS) {
-            if (ND < 0.0f) { addToIndiceStack(p, m.Ni); n1 = p.s[1]; n2 = p.s[0]; }           // :833-836
-            else { n1 = p.s[0]; n2 = p.s[1]; removeFirstOfIndiceStack(p); }                    // :838-840
+            const float s0 = indiceStackSlot<STK>(sc, p, 0), s1 = indiceStackSlot<STK>(sc, p, 1);
+            // :833-836: slot 1 after the push is the old slot 0 — unless the stack was empty (the shift loop does not run: slot 1 keeps its stale
+            // value) or full (the push is dropped: both slots stay)
+            if (ND < 0.0f) { const bool full = p.stackSize >= 10; n1 = (full || p.stackSize == 0) ? s1 : s0; n2 = full ? s0 : m.Ni; addToIndiceStack<STK>(p, (uint32_t)m.niCode); }
+            else { n1 = s0; n2 = s1; removeFirstOfIndiceStack<STK>(p); }                       // :838-840
         }
         w = chooseLobe<FAST>(m, n1, n2, N, D, p.rng);         // :843 up to the lobe decision
         Ke = v3(m.Ke[0], m.Ke[1], m.Ke[2]); albedoKd = v3(m.Kd[0], m.Kd[1], m.Kd[2]); albedoKs = v3(m.Ks[0], m.Ks[1], m.Ks[2]);

@@ -54,6 +54,11 @@ constexpr int BLOCK = 256;
 #endif
 constexpr int SHADE_BLOCK = SHADE_BLOCK_SIZE;     // threads per block of the shading kernel: one scheduler atomic per block per launch
 constexpr int TILE_W = 32, TILE_H = 8;
+// inner-node records of the hand-written intersect kernel above this many bytes (in the 80-B form) take the 64-B form: what an XCD's 4 MB L2 holds
+// beside the triangles and the path state streaming through it (measured: profiles/r04_*_node_records.txt)
+#ifndef ASM_NODES_80B_LIMIT
+#define ASM_NODES_80B_LIMIT (2 << 20)
+#endif
 
 struct FrameIn { float params[12]; float origin[3]; float rotation[3]; float mouse[3]; };
 
@@ -80,7 +85,8 @@ static_assert(offsetof(Control, exhausted) == 4 && offsetof(Control, qCount) == 
 __device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return ctl->exhausted[(iter + 3) & 3] != 0; }
 
 struct State {              // SoA path pool, float4 groups (see header comment)
-    float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *S1, *S2, *H;
+    float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *H;
+    uint2* J;               // (frame slot of the stream, accumulator slot) of the slot's job: written when the job starts, read when it ends
     float4* HX;             // (u, v, id) of the closest triangle behind an ellipsoid hit; only for scenes whose ellipsoids carry texture-mapped materials
 };
 
@@ -143,18 +149,20 @@ __global__ void k_frame_setup(DevScene sc, const FrameIn* in, FrameConst* fc, El
     fc->focus = (fc->AUTO_FOCUS == 1.0f && mid > 0.0f) ? mid : fc->FOCAL_DISTANCE;
 }
 
-__device__ __forceinline__ void storePath(const State& st, unsigned i, const Path& p, bool trans) {
+// Path state in memory (16 B per lane per group, consecutive lanes on consecutive slots):
+//   G0 = O.xyz, D.x    G1 = D.yz, rngState, flags    G2 = throughput.rgb, index-stack codes (3-bit scenes)    G4 = sum over samples.rgb, pixel x | y << 16
+//   G3 = incLight.rgb of the running sample, touched only while FL_INCNZ (pt_device.hpp)      J = (frame slot, accumulator slot), job start / job end only
+//   G5 = RAY_ENTER_LOCATION, DISTANCE_TRAVELED and S0 = index-stack codes of an 8-bit scene: scenes with transmissive materials only
+template <int STK>
+__device__ __forceinline__ void storePath(const State& st, unsigned i, const Path& p) {
     st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
     st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
-    st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.pix));
-    st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
-    st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.ls));
-    if (trans) {
-        st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
-        st.S0[i] = make_float4(p.s[0], p.s[1], p.s[2], p.s[3]);
-        st.S1[i] = make_float4(p.s[4], p.s[5], p.s[6], p.s[7]);
-        st.S2[i] = make_float4(p.s[8], p.s[9], 0.0f, 0.0f);
-    }
+    st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.sc0));
+    st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f);      // (job starts only; directDiffuse reads the group for every lane)
+    st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix));
+    st.J[i] = make_uint2(p.fi, p.ls);
+    if (STK) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
+    if (STK == 8) st.S0[i] = make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f);
 }
 
 // A new pixel-frame job (one fragment-shader invocation): fresh "globals" (SURVEY.md Q-1), rngState = index + u_seed.
@@ -173,15 +181,15 @@ __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, u
     p.sample = 0;
     p.applyAbs = false; p.inObj = false;
     p.enter = v3(0.0f); p.dist = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 10; i++) p.s[i] = 0.0f;
+    p.sc0 = 0u; p.sc1 = 0u; p.sc2 = 0u;                         // every slot of the index stack 0.0 (dictionary code 0)
     p.stackSize = 0;
+    p.incNZ = false; p.inc = v3(0.0f);
     p.alive = true;
 }
 
 // Every dead slot of the pool asks for a job (one scheduler atomic per block) and, if one is left, starts it: the start of
 // a frame stream (all slots dead) and the restart after the pool ran dry between two batches.
-template <bool TRANS, bool FAST>
+template <int STK, bool FAST>
 __global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp, State st, int nSlots, Control* ctl) {
     __shared__ unsigned sCnt[BLOCK / 64], sBase;
     const unsigned mode = ctl->needRevive;
@@ -193,8 +201,8 @@ __global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp
         const FrameConst& fc = *fcp;
         Path p;
         startJob(b, fc, i, p);
-        startSample<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
-        storePath(st, i, p, TRANS);
+        startSample<STK, FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
+        storePath<STK>(st, i, p);
         st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
         return;
     }
@@ -218,8 +226,8 @@ __global__ void __launch_bounds__(BLOCK) k_revive(Batch b, const FrameConst* fcp
     const FrameConst& fc = *fcp;
     Path p;
     startJob(b, fc, job, p);
-    startSample<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
-    storePath(st, i, p, TRANS);
+    startSample<STK, FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p);
+    storePath<STK>(st, i, p);
     st.H[i] = make_float4(1e30f, 0.0f, 0.0f, __int_as_float(PRIM_NONE));
 }
 
@@ -524,9 +532,10 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 // ran one instruction stream each; once the kernel had become memory-bound the permuted accesses cost more than the
 // divergence saved: 2-4 % per step on C2-C5, profiles/; likewise the dense LDS-listed pass that used to compute the camera
 // rays of new samples for the whole block.)
-template <bool TRANS, bool STATS, bool DIRECT, bool TEX, bool FAST = false>
+template <int STK, bool STATS, bool DIRECT, bool TEX, bool FAST = false>
 __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
                                                  int nSlots, Control* ctl) {
+    constexpr bool TRANS = STK != 0;
     __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long ltMask = (1ull << lane) - 1ull;
@@ -538,47 +547,50 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     if (writeQueue && blockIdx.x == 0 && threadIdx.x == 0) ctl->exhausted[(iter + 1) & 3] = 1u;     // sticky, also through an empty launch
     if (blockIdx.x * SHADE_BLOCK >= n) return;                           // the grid is sized by the host's last known bound
     // ---- 1. the slot and its state: every load of the segment is issued here, in one batch — the kernel's critical path is
-    // memory round trips, not bytes.  Only the deep part of the index stack and the medium-entry group wait for the flags.
+    // memory round trips, not bytes.  Only the groups few lanes need wait for the flags: incLight (G3) and the medium-entry group (G5).
     const unsigned q = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     const bool valid = q < n;
     const unsigned i = valid ? (queue ? queue[q] : q) : 0u;
-    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, s1 = g0, s2 = g0, g5 = g0;
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, g5 = g0;
     if (valid) {
-        g1 = st.G1[i]; g0 = st.G0[i]; h = st.H[i]; g2 = st.G2[i]; g3 = st.G3[i]; g4 = st.G4[i];
-        if (TRANS) s0 = st.S0[i];
+        g1 = st.G1[i]; g0 = st.G0[i]; h = st.H[i]; g2 = st.G2[i]; g4 = st.G4[i];
+        if (STK == 8) s0 = st.S0[i];
+        if (DIRECT) g3 = st.G3[i];
     }
     const bool live = valid && (__float_as_uint(g1.w) & FL_ALIVE);
     Path p;
     p.alive = false;
     bool jobDone = false, needStart = false;
     unsigned nSamp = 0;
-    // Groups are written back only when this segment changed them: sum (G4) at sample end; RAY_ENTER_LOCATION /
-    // DISTANCE_TRAVELED (G5) when the transmission lobe won; index-stack slots 4-7 / 8-9 (S1/S2) are not even fetched
-    // unless the stack is that deep (push/pop never touch slots above the current size, frag.glsl:142-158).
-    bool touchS1 = false, touchS2 = false, sampleDone = false, newJob = false, isProbe = false;
+    // Groups are written back only when this segment changed them: sum (G4) at sample end; RAY_ENTER_LOCATION / DISTANCE_TRAVELED (G5) when the
+    // transmission lobe won; incLight (G3) when it is not zero and not what memory holds.
+    bool sampleDone = false, newJob = false, isProbe = false, incInMemory = false;
     float4 g3in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) {
         unpackFlags(p, __float_as_uint(g1.w));
+        // incLight of the running sample: +0.0 in every component unless the path has met an emitter and gone on (FL_INCNZ): only those lanes fetch it.
+        // (directDiffuse parks its probe state in the group: that mode reads and writes it for every lane.)
+        incInMemory = DIRECT || p.incNZ;
+        if (!DIRECT && p.incNZ) g3 = st.G3[i];
         if (TRANS) {
-            touchS1 = p.stackSize >= 4; touchS2 = p.stackSize >= 8;
-            if (touchS1) s1 = st.S1[i];
-            if (touchS2) s2 = st.S2[i];
             // RAY_ENTER_LOCATION / DISTANCE_TRAVELED are read only while the path is inside a medium or owes an absorption term;
             // a transmission event on any other path fetches them late (shadeSegment), which is rare
             p.g5loaded = p.inObj || p.applyAbs;
             if (p.g5loaded) g5 = st.G5[i];
         }
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
-        p.col = v3(g2.x, g2.y, g2.z); p.pix = __float_as_uint(g2.w);
-        p.inc = v3(g3.x, g3.y, g3.z); p.fi = __float_as_uint(g3.w);
-        p.sum = v3(g4.x, g4.y, g4.z); p.ls = __float_as_uint(g4.w);
+        p.col = v3(g2.x, g2.y, g2.z);
+        p.inc = incInMemory ? v3(g3.x, g3.y, g3.z) : v3(0.0f);
+        p.sum = v3(g4.x, g4.y, g4.z); p.pix = __float_as_uint(g4.w);
+        p.fi = 0u; p.ls = 0u;                                       // the job's (frame slot, accumulator slot) wait in J until the job ends
         p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5dirty = false;
         if (!TRANS) p.g5loaded = true;
-        g3in = g3;
-        p.s[0] = s0.x; p.s[1] = s0.y; p.s[2] = s0.z; p.s[3] = s0.w; p.s[4] = s1.x; p.s[5] = s1.y; p.s[6] = s1.z; p.s[7] = s1.w; p.s[8] = s2.x; p.s[9] = s2.y;
+        g3in = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f);
+        if (STK == 8) { p.sc0 = __float_as_uint(s0.x); p.sc1 = __float_as_uint(s0.y); p.sc2 = __float_as_uint(s0.z); }
+        else { p.sc0 = __float_as_uint(g2.w); p.sc1 = 0u; p.sc2 = 0u; }
         isProbe = DIRECT && p.probe;
         if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w), st.HX, i);      // RAYTRACING == 0 (frag.glsl:911-912)
-        else sampleDone = shadeSegment<TRANS, TEX, FAST>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i);
+        else sampleDone = shadeSegment<STK, TEX, FAST>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i);
         if (sampleDone) {
             p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
             p.sample++;
@@ -586,8 +598,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             if ((float)p.sample < fc.SAMPLE_RES) {                 // loop condition :898
                 needStart = true;
             } else {
+                const uint2 job = st.J[i];
                 float sr = fc.SAMPLE_RES;
-                b.colbuf[(size_t)(p.fi % b.ringFrames) * b.nSlots + p.ls] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
+                b.colbuf[(size_t)(job.x % b.ringFrames) * b.nSlots + job.y] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
                 jobDone = true;
             }
         }
@@ -634,23 +647,23 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         }
     }
     // ---- 5. a lane that starts a sample computes its camera ray itself (frag.glsl:899-908); every store stays in slot order
-    if (needStart) { tracePrologue(p); cameraRay<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p.rng, p.O, p.D); }
+    if (needStart) { tracePrologue<STK>(p); cameraRay<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p.rng, p.O, p.D); }
     if (live) {
+        {   // incLight leaves zero only at an emitter whose sample goes on, and returns to it with the next sample (tracePrologue): most segments
+            // neither read nor write the group
+            const bool nz = (__float_as_uint(p.inc.x) | __float_as_uint(p.inc.y) | __float_as_uint(p.inc.z)) != 0u;
+            const bool changed = __float_as_uint(p.inc.x) != __float_as_uint(g3in.x) || __float_as_uint(p.inc.y) != __float_as_uint(g3in.y) ||
+                                 __float_as_uint(p.inc.z) != __float_as_uint(g3in.z);
+            if (DIRECT) { if (changed) st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f); p.incNZ = false; }
+            else { if (nz && (changed || !incInMemory)) st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f); p.incNZ = nz; }
+        }
         st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
         st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
-        st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.pix));
-        {   // incoming light changes only at emitters, at the sky and at sample boundaries: most segments leave the group as it was
-            const float4 g3out = make_float4(p.inc.x, p.inc.y, p.inc.z, __uint_as_float(p.fi));
-            if (__float_as_uint(g3out.x) != __float_as_uint(g3in.x) || __float_as_uint(g3out.y) != __float_as_uint(g3in.y) ||
-                __float_as_uint(g3out.z) != __float_as_uint(g3in.z) || __float_as_uint(g3out.w) != __float_as_uint(g3in.w)) st.G3[i] = g3out;
-        }
-        if (sampleDone) st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.ls));
-        if (TRANS) {
-            st.S0[i] = make_float4(p.s[0], p.s[1], p.s[2], p.s[3]);
-            if (touchS1 || newJob) st.S1[i] = make_float4(p.s[4], p.s[5], p.s[6], p.s[7]);
-            if (touchS2 || newJob) st.S2[i] = make_float4(p.s[8], p.s[9], 0.0f, 0.0f);
-            if (p.g5dirty || newJob) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
-        }
+        st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.sc0));
+        if (sampleDone) st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix));
+        if (newJob) st.J[i] = make_uint2(p.fi, p.ls);
+        if (STK == 8) st.S0[i] = make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f);
+        if (TRANS) { if (p.g5dirty || newJob) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist); }
     }
     if (STATS) {                                  // statistics (count mode only): one atomic per wave
         unsigned long long lm = __ballot(live && !isProbe);      // a thickness probe is part of the same directDiffuse call
@@ -720,7 +733,7 @@ __global__ void __launch_bounds__(64) k_debug_heatmap(DevScene sc, Batch b, cons
 __global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, unsigned fEnd, Control* ctl) {
     unsigned i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= (unsigned)nSlots) return;
-    if ((__float_as_uint(st.G1[i].w) & FL_ALIVE) && __float_as_uint(st.G3[i].w) < fEnd) ctl->oldestBusy = 1u;
+    if ((__float_as_uint(st.G1[i].w) & FL_ALIVE) && st.J[i].x < fEnd) ctl->oldestBusy = 1u;
 }
 
 // fragColor -> UNORM8 framebuffer -> glReadPixels(GL_RGB) -> Java signed-byte packing -> vertical flip (dispatch.java:804-833)
@@ -784,6 +797,7 @@ __global__ void k_debug_math(int fn, const float* x, const float* y, float* out,
         case 6: { uint32_t st = __float_as_uint(x[i]); NextRandom(st); r = __uint_as_float(st); break; }                     // state after one call
         case 7: { uint32_t st = __float_as_uint(x[i]); r = __uint_as_float(NextRandom(st)); break; }                         // result of that call
         case 8: { uint32_t st = __float_as_uint(x[i]); r = random_(st); break; }                                             // random()
+        case 9: r = unorm8((uint32_t)x[i]); break;                                                                           // byte / 255.0f as the samplers evaluate it
         default: r = __builtin_nanf("");
     }
     out[i] = r;
@@ -804,13 +818,14 @@ struct pt_ctx {
     std::vector<uint8_t> sky; int skyW = 0, skyH = 0;
     struct HostTex { std::vector<uint8_t> rgba; int w = 0, h = 0; };
     std::vector<HostTex> textures;          // bindless table beyond the sky (index 0 mirrors `sky`)
-    float4* dTexels = nullptr; TexRec* dTexTable = nullptr;      // all textures beyond the sky in one allocation + the bindless-style table
+    uchar4* dTexels = nullptr; TexRec* dTexTable = nullptr;      // all textures beyond the sky in one allocation + the bindless-style table
     bool sceneDirty = true, frameInDirty = true;
     bool trans = false, anySubsurface = false, ambiguousTriObj = false, anyMaps = false, ellipMaps = false; int* dTriObj = nullptr;
     int stackDepth = 1;
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
-    float4* dSky = nullptr;
+    uchar4* dSky = nullptr; float* dNiTable = nullptr;
+    int niBits = 0;                 // index-stack encoding of the path state: 0 no transmissive material (the stack is unobservable), 3 or 8 bits per slot
     unsigned char* dDisplay = nullptr;      // scratch of pt_read_display (W*H*3 bytes, allocated on first use)
     DevScene sc{};
     // shard
@@ -819,7 +834,7 @@ struct pt_ctx {
     float4* dImage[IMAGES] = {nullptr, nullptr, nullptr, nullptr}; int curImage = 0;      // FRAME images (more than one only after pt_next_image)
     // path pool
     int poolSlots = 0;              // 0 = automatic: jobs/5 clamped to [2^20, 2^22] (enough rays per lane for the in-wave refill, short tail)
-    int poolActive = 0; int allocSlots = 0; bool allocTrans = false, allocHX = false;
+    int poolActive = 0; int allocSlots = 0; int allocNiBits = -1; bool allocHX = false;
     State st{};
     unsigned* dQueue[2] = {nullptr, nullptr};      // dense slot queues of the batch tail, by iteration parity
     float4* dColbuf = nullptr; int* dSeeds = nullptr; int ringFrames = 0;      // per-frame rings of the stream (Batch)
@@ -837,7 +852,8 @@ struct pt_ctx {
     int ldsBudget = 20 * 1024;
     int extendMode = 2;             // 0: one block per 256 lanes (k_extend), 1: persistent blocks (k_extend_persist), 2: the hand-written form of 1
                                     //    (pt_extend_gfx950.s) for the scenes it takes, 1 for the others
-    float* dNodes80 = nullptr;      // node records of the hand-written kernel: 80 B, (min pair, max pair, min pair) per axis + the two references
+    float* dNodes80 = nullptr;      // node records of the hand-written kernel: the two references + (min pair, max pair, min pair) per axis (80 B), or + pad + (min pair, max pair) (64 B)
+    int asmNodeStride = 80, asmNodeLayout = -1;      // bytes per record as built; pt_set_option 19: -1 automatic, 0 80-B, 1 64-B
     void* dAsmDbg = nullptr;
     std::string asmError;           // a failed load / launch of the hand-written kernel (surfaces as PT_ERR_HIP from the render call)
     uint64_t asmLaunches = 0;
@@ -851,6 +867,7 @@ struct pt_ctx {
     bool noneMinSet = false;        // pt_set_option 3 was used
     int streamsOnDevice = 1;        // streams of the same multi-stream context on this context's GPU (pt_create_multi)
     bool extendCacheSet = false;    // pt_set_option 6 was used: the tile size is the caller's
+    bool forceNiBits8 = false;      // pt_set_option 18 (tests): 8-bit index-stack codes even when the scene's dictionary fits 3 bits
     bool fastContract = false, streamFast = false;      // the relaxed numeric contract (pt_set_option 16) as set / as the running stream was started with
     int asmLoop = -1;               // hand-written kernel's main loop: -1 automatic, 0 phase-voting, 1 fused trip (pt_set_option 14)
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
@@ -930,6 +947,18 @@ int buildScene(pt_ctx* c) {
         if (r.subsurface > 0.0f) c->anySubsurface = true;
         if (r.hasMaps) c->anyMaps = true;
     }
+    // the refraction-index dictionary (pt_device.hpp, DevScene::ni8): 0.0f, 1.0029f, then every distinct Ni bit pattern among the materials
+    std::vector<float> niDict = {0.0f, 1.0029f};
+    for (int m = 0; m < nMat; m++) {
+        uint32_t bits; std::memcpy(&bits, &mats[m].Ni, 4);
+        int code = -1;
+        for (size_t k = 0; k < niDict.size(); k++) { uint32_t kb; std::memcpy(&kb, &niDict[k], 4); if (kb == bits) { code = (int)k; break; } }
+        if (code < 0) { code = (int)niDict.size(); niDict.push_back(mats[m].Ni); }
+        mats[m].niCode = code;
+    }
+    if (c->trans && niDict.size() > 256) return fail(PT_ERR_UNSUPPORTED, "more than 254 distinct refraction indices (Ni) among the materials of a scene with transmissive materials");
+    c->niBits = !c->trans ? 0 : ((niDict.size() <= 8 && !c->forceNiBits8) ? 3 : 8);
+    niDict.resize(std::max<size_t>(niDict.size(), 8), 0.0f);
     // objects / BVH
     int numObj = c->objidx[0];
     if (numObj < 0 || (size_t)numObj + 1 > c->objidx.size()) return fail(PT_ERR_SCENE, "objIndices[0] exceeds the buffer");
@@ -1026,22 +1055,30 @@ int buildScene(pt_ctx* c) {
         nodeRecs.push_back(f4(A[0], B[0], A[1], B[1])); nodeRecs.push_back(f4(A[2], B[2], A[3], B[3])); nodeRecs.push_back(f4(A[4], B[4], A[5], B[5]));
         nodeRecs.push_back(f4(asf((uint32_t)refOf(L)), asf((uint32_t)refOf(R)), 0, 0));
     }
-    // The hand-written intersect kernel (pt_extend_gfx950.s) reads 80-B node records: per axis (Lmin, Rmin | Lmax, Rmax | Lmin, Rmin), so that
-    // a lane whose direction component is negative starts 8 B further in and receives (near pair, far pair); then the two references.
-    std::vector<float> nodes80(std::max<size_t>(order.size(), 1) * 20, 0.0f);
+    // The hand-written intersect kernel (pt_extend_gfx950.s) reads its own node records.  80 B: the two references, then per axis (Lmin, Rmin | Lmax,
+    // Rmax | Lmin, Rmin), so that a lane whose direction component is negative starts 8 B further in and receives (near pair, far pair) without a
+    // min / max.  Trees that do not fit the caches pay for those bytes on every node visit (C4: 552 B per segment, the chip at 0.61 of its HBM peak):
+    // they get 64-B records — references, pad, (Lmin, Rmin | Lmax, Rmax) per axis — and the kernel's min/max step (pt_set_option 19 overrides).
+    const size_t nInner = order.size();
+    const int asmStride = c->asmNodeLayout == 0 ? 80 : c->asmNodeLayout == 1 ? 64 : (nInner * 80 > (size_t)ASM_NODES_80B_LIMIT ? 64 : 80);
+    const int W_ = asmStride / 4;
+    std::vector<float> nodes80(std::max<size_t>(nInner, 1) * W_, 0.0f);
     bool boxesOrdered = true, anyEmpty = false;
-    for (size_t k = 0; k < order.size(); k++) {
+    for (size_t k = 0; k < nInner; k++) {
         const int n = order[k], L = childOf(n, 0), R = childOf(n, 1);
         const float* A = c->bvhdata.data() + 8 * (size_t)L; const float* B = c->bvhdata.data() + 8 * (size_t)R;
-        float* o = nodes80.data() + 20 * k;
+        float* o = nodes80.data() + (size_t)W_ * k;
         for (int ax = 0; ax < 3; ax++) {
-            o[6 * ax] = A[ax]; o[6 * ax + 1] = B[ax]; o[6 * ax + 2] = A[3 + ax]; o[6 * ax + 3] = B[3 + ax]; o[6 * ax + 4] = A[ax]; o[6 * ax + 5] = B[ax];
+            float* g = asmStride == 80 ? o + 2 + 6 * ax : o + 4 + 4 * ax;
+            g[0] = A[ax]; g[1] = B[ax]; g[2] = A[3 + ax]; g[3] = B[3 + ax];
+            if (asmStride == 80) { g[4] = A[ax]; g[5] = B[ax]; }
             if (!(A[ax] <= A[3 + ax]) || !(B[ax] <= B[3 + ax])) boxesOrdered = false;      // min > max or a NaN: only the min/max form of rayBox is right
         }
         const int lr = refOf(L), rr = refOf(R);
-        std::memcpy(&o[18], &lr, 4); std::memcpy(&o[19], &rr, 4);
+        std::memcpy(&o[0], &lr, 4); std::memcpy(&o[1], &rr, 4);
         if (lr == REF_EMPTY || rr == REF_EMPTY) anyEmpty = true;
     }
+    c->asmNodeStride = asmStride;
     std::vector<ObjRoot> roots(std::max(numObj, 8));           // (the hand-written kernel fetches root records in batches of four: at least eight exist)
     for (int o = 0; o < numObj; o++) {
         int r = c->objidx[1 + o]; const float* A = c->bvhdata.data() + 8 * (size_t)r;
@@ -1081,30 +1118,29 @@ int buildScene(pt_ctx* c) {
     if ((rc = uploadVec((void**)&c->dRoots, roots.data(), roots.size() * sizeof(ObjRoot), s))) return rc;
     if ((rc = uploadVec((void**)&c->dEllip, er.data(), er.size() * sizeof(EllipRec), s))) return rc;
     if ((rc = uploadVec((void**)&c->dMats, mats.data(), mats.size() * sizeof(MatRec), s))) return rc;
-    std::vector<float4> skyf((size_t)c->skyW * c->skyH);
-    for (size_t k = 0; k < skyf.size(); k++)
-        skyf[k] = f4((float)c->sky[4 * k] / 255.0f, (float)c->sky[4 * k + 1] / 255.0f, (float)c->sky[4 * k + 2] / 255.0f, (float)c->sky[4 * k + 3] / 255.0f);
-    if ((rc = uploadVec((void**)&c->dSky, skyf.data(), skyf.size() * 16, s))) return rc;
+    // textures stay the RGBA8 texels the caller uploaded (dispatch.java:349-354: GL_RGBA8); byte / 255.0f happens at fetch (unorm8, pt_device.hpp)
+    if ((rc = uploadVec((void**)&c->dSky, c->sky.data(), (size_t)c->skyW * c->skyH * 4, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dNiTable, niDict.data(), niDict.size() * 4, s))) return rc;
     // the texture table beyond the sky: ONE allocation and one asynchronous copy for all textures
     std::vector<TexRec> table(std::max<size_t>(c->textures.size(), 1));
     table[0].data = c->dSky; table[0].w = c->skyW; table[0].h = c->skyH;
-    std::vector<float4> texels; std::vector<size_t> texOff(table.size(), 0);
+    std::vector<uint8_t> texels; std::vector<size_t> texOff(table.size(), 0);
     for (size_t ti = 1; ti < c->textures.size(); ti++) {
         const pt_ctx::HostTex& T = c->textures[ti];
         table[ti].data = nullptr; table[ti].w = T.w; table[ti].h = T.h;
         if (T.rgba.empty()) continue;
-        texOff[ti] = texels.size();
-        const size_t nTex = (size_t)T.w * T.h;
-        for (size_t k = 0; k < nTex; k++)
-            texels.push_back(f4((float)T.rgba[4 * k] / 255.0f, (float)T.rgba[4 * k + 1] / 255.0f, (float)T.rgba[4 * k + 2] / 255.0f, (float)T.rgba[4 * k + 3] / 255.0f));
+        texOff[ti] = texels.size() / 4;
+        texels.insert(texels.end(), T.rgba.begin(), T.rgba.begin() + (size_t)T.w * T.h * 4);
     }
-    if ((rc = uploadVec((void**)&c->dTexels, texels.data(), texels.size() * 16, s))) return rc;
+    if ((rc = uploadVec((void**)&c->dTexels, texels.data(), texels.size(), s))) return rc;
     for (size_t ti = 1; ti < c->textures.size(); ti++) if (!c->textures[ti].rgba.empty()) table[ti].data = c->dTexels + texOff[ti];
     if ((rc = uploadVec((void**)&c->dTexTable, table.data(), table.size() * sizeof(TexRec), s))) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     DevScene& sc = c->sc;
     sc.nodes = c->dNodes; sc.nNodes = (int)order.size(); sc.tris = c->dTris; sc.nTriRecs = (int)(triRecs.size() / 3);
     sc.shade = c->dShade; sc.nTris = (int)nTris; sc.triObj = c->dTriObj; sc.roots = c->dRoots; sc.numObj = numObj; sc.ellip = c->dEllip; sc.numEllip = nE;
+    for (int k = 0; k < 8; k++) sc.ni8[k] = niDict[k];
+    sc.niTable = c->dNiTable;
     sc.mats = c->dMats; sc.numMat = nMat; sc.sky = c->dSky; sc.skyW = c->skyW; sc.skyH = c->skyH; sc.tex = c->dTexTable; sc.numTex = (int)table.size();
     // LDS tile: as many leading (top-of-tree) node records and triangle records as the budget allows
     int budget = c->ldsBudget - c->stackDepth * BLOCK * 4;
@@ -1128,10 +1164,10 @@ int buildScene(pt_ctx* c) {
     // which scenes the hand-written kernel takes (the others run on the compiled k_extend_persist, same results)
     for (int o = 0; o < numObj; o++) if (roots[o].ref == REF_EMPTY) anyEmpty = true;
     c->asmWhyNot.clear();
-    if (nE > 0) c->asmWhyNot = "ellipsoids";
-    else if (numObj < 1 || numObj > 8) c->asmWhyNot = "no BVH or more than 8";
+    if (numObj < 1 || numObj > 1024) c->asmWhyNot = "no BVH or more than 1024";
+    else if (ellipMaps) c->asmWhyNot = "ellipsoids with texture-mapped materials";
     else if (anyEmpty) c->asmWhyNot = "a leaf without triangles";
-    else if (!boxesOrdered) c->asmWhyNot = "a node box with min > max or a NaN";
+    else if (!boxesOrdered && asmStride == 80) c->asmWhyNot = "a node box with min > max or a NaN";      // (the 64-B records' min/max step is rayBox as written)
     else if (c->stackMode == 2) c->asmWhyNot = "tree too large for 18-bit stack entries";
     else if (triRecs.size() / 3 >= (1u << 24) || order.size() >= (1u << 24)) c->asmWhyNot = "more than 2^24 records";
     c->asmEligible = c->asmWhyNot.empty();
@@ -1141,21 +1177,22 @@ int buildScene(pt_ctx* c) {
 
 int ensurePool(pt_ctx* c, int capacity) {               // capacity >= poolActive: room for a pool that grows while a stream runs
     capacity = std::max(capacity, c->poolActive);
-    if (c->allocSlots >= capacity && c->allocTrans == c->trans && c->allocHX == c->ellipMaps) return 0;
+    if (c->allocSlots >= capacity && c->allocNiBits == c->niBits && c->allocHX == c->ellipMaps) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->allocSlots = 0;                                            // until every allocation below has succeeded there is no pool
-    float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.G5, &c->st.S0, &c->st.S1, &c->st.S2, &c->st.H, &c->st.HX};
+    float4** groups[] = {&c->st.G0, &c->st.G1, &c->st.G2, &c->st.G3, &c->st.G4, &c->st.H, &c->st.G5, &c->st.S0, &c->st.HX};
     for (auto g : groups) if (*g) { HIP_TRY(hipFree(*g)); *g = nullptr; }
+    if (c->st.J) { HIP_TRY(hipFree(c->st.J)); c->st.J = nullptr; }
     for (unsigned** q : {&c->dQueue[0], &c->dQueue[1]}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     size_t n = (size_t)capacity;
-    for (int k = 0; k < 11; k++) {
-        bool transOnly = (k >= 5 && k <= 8);
-        if ((transOnly && !c->trans) || (k == 10 && !c->ellipMaps)) continue;
+    for (int k = 0; k < 9; k++) {
+        if ((k == 6 && c->niBits == 0) || (k == 7 && c->niBits != 8) || (k == 8 && !c->ellipMaps)) continue;      // G5: transmissive scenes; S0: 8-bit index-stack codes; HX: mapped ellipsoids
         HIP_TRY(hipMalloc((void**)groups[k], n * 16));
     }
+    HIP_TRY(hipMalloc((void**)&c->st.J, n * 8));
     HIP_TRY(hipMalloc((void**)&c->dQueue[0], n * 4));
     HIP_TRY(hipMalloc((void**)&c->dQueue[1], n * 4));
-    c->allocSlots = capacity; c->allocTrans = c->trans; c->allocHX = c->ellipMaps;
+    c->allocSlots = capacity; c->allocNiBits = c->niBits; c->allocHX = c->ellipMaps;
     return 0;
 }
 
@@ -1198,8 +1235,10 @@ struct EpAsmArgs {
     int ldsNodes, ldsTris, numObj, iter, nSlots, refillMin, keepEighths, noneMin;
     unsigned divM, divS, nWaves, mode;      // mode: 1 the fused trip, 0 the phase-voting loop
     void* dbg;                      // developer builds of the assembly (-DPT_ASM_DEBUG): 32 B per wave
+    const void* ellip; int numEllip, nodeStride;      // EllipRec array (rotation matrices by k_frame_setup); bytes per node record (80 or 64)
 };
-static_assert(sizeof(EpAsmArgs) == 120, "EpAsmArgs layout is part of the assembly");
+static_assert(sizeof(EpAsmArgs) == 136 && offsetof(EpAsmArgs, ellip) == 120, "EpAsmArgs layout is part of the assembly");
+static_assert(sizeof(EllipRec) == 128 && offsetof(EllipRec, rotated) == 32 && offsetof(EllipRec, R) == 48, "EllipRec layout is part of the assembly");
 #ifndef PT_EXTEND_INC
 #define PT_EXTEND_INC "pt_extend_hsaco.inc"
 #endif
@@ -1234,18 +1273,20 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // C5 +7 %, C2 +-0).  When the context's streams share the GPU the small blocks win (their slots free one by one for the other stream's
     // shading blocks: 1024-thread blocks -4...7 %), and so they do for a launch too small to give every CU its two large blocks.
     const bool sharedGpu = c->streamsOnDevice > 1;
-    const size_t perLane = (size_t)sc.numObj * 4 + (size_t)c->stackDepth * 2;      // root-box distances + traversal stack of one lane
-    const bool largeFits = 2 * (perLane * 1024 + 48 + 16384) <= (size_t)160 * 1024;      // two large blocks per CU with at least a 16 KB tile each (deep trees: stacks)
+    const bool lazyRoots = sc.numObj > 8;                      // more than 8 BVHs: root records in LDS, tested when a BVH's turn comes (no per-lane distances)
+    const size_t perLane = (lazyRoots ? 0 : (size_t)sc.numObj * 4) + (size_t)c->stackDepth * 2;      // root-box distances + traversal stack of one lane
+    const size_t rootBytes = lazyRoots ? (size_t)sc.numObj * 32 : 0;
+    const bool largeFits = 2 * (perLane * 1024 + rootBytes + 48 + 16384) <= (size_t)160 * 1024;      // two large blocks per CU with at least a 16 KB tile each (deep trees: stacks)
     const int TPB = c->asmTpb ? c->asmTpb : (!sharedGpu && largeFits && pr.launched >= (uint64_t)c->numCUs * 2048 ? 1024 : 256);
     const int BPW = TPB / 256;                                  // how many 256-thread blocks one block stands for
-    const size_t fixed = (size_t)sc.numObj * 4 * TPB + 48 + (size_t)c->stackDepth * 2 * TPB;      // root-box distances, root references + ray cursor, traversal stacks
+    const size_t fixed = (lazyRoots ? rootBytes : (size_t)sc.numObj * 4 * TPB) + 48 + (size_t)c->stackDepth * 2 * TPB;      // root-box distances (or root records), root references + ray cursor, traversal stacks
     const size_t ldsPerCU = 160 * 1024;                        // gfx950; one block may take all of it
     if (fixed + 2048 > ldsPerCU) return false;
     // Blocks per CU and tile: alone on the GPU the kernel wants every wave slot (8 blocks of 256 threads, 8 KB tile).  When the context's streams
     // share the GPU (pt_create_multi with a device listed more than once) 6 blocks with a 16 KB tile are worth more: the two slots per SIMD it
     // leaves let the other stream's shading blocks run beside it instead of behind it (C3 +3.5 %, C4 +3 %, C5 +2.5 % over 8 blocks,
     // profiles/r03_d_blocks_per_cu_and_tile.txt) — unless the whole scene fits the small tile anyway (C2).
-    const bool wholeSceneInSmallTile = (size_t)sc.nNodes * 80 + (size_t)sc.nTriRecs * 48 <= 8192;
+    const bool wholeSceneInSmallTile = (size_t)sc.nNodes * (size_t)c->asmNodeStride + (size_t)sc.nTriRecs * 48 <= 8192;
     const bool shareSlots = c->streamsOnDevice > 1 && !wholeSceneInSmallTile;
     const int maxBlocks = std::max(1, (c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : (shareSlots ? 6 : 8)) / BPW);
     const size_t tileWanted = c->extendCacheSet ? (size_t)c->extendCacheBytes : (shareSlots ? 16384 : 8192) * (size_t)BPW;
@@ -1256,9 +1297,10 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
         if (fixed + cb + 16 > perBlock && perBlock > fixed + 16 + 2048) cb = std::min(cb, (perBlock - fixed - 16) & ~(size_t)15);
     }
     EpAsmArgs a{};
-    a.ldsNodes = (int)std::min<size_t>((size_t)sc.nNodes, cb / 80);
-    a.ldsTris = (a.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)a.ldsNodes * 80) / 48) : 0;
-    size_t lds = (size_t)a.ldsNodes * 80 + (size_t)a.ldsTris * 48 + fixed;
+    const size_t NS = (size_t)c->asmNodeStride;
+    a.ldsNodes = (int)std::min<size_t>((size_t)sc.nNodes, cb / NS);
+    a.ldsTris = (a.ldsNodes == sc.nNodes) ? (int)std::min<size_t>((size_t)sc.nTriRecs, (cb - (size_t)a.ldsNodes * NS) / 48) : 0;
+    size_t lds = (size_t)a.ldsNodes * NS + (size_t)a.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
     int perCU = std::max(1, std::min((int)(ldsPerCU / lds), maxBlocks));
     int grid = c->numCUs * perCU;
@@ -1267,6 +1309,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     if (loadAsmKernel(c, variant)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
+    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride;
     a.numObj = sc.numObj; a.iter = pr.iter; a.nSlots = (int)pr.launched; a.refillMin = c->refillMin; a.keepEighths = c->innerKeepEighths; a.noneMin = c->noneMin;
     // main loop: the fused trip with fetch-at-decision, unless the whole scene sits in the LDS tile — then no fetch is worth hiding and the
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)
@@ -1420,14 +1463,16 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             }
 #define SHADE_ARGS dim3(std::max(1, (int)((pr.launched + SHADE_BLOCK - 1) / SHADE_BLOCK))), dim3(SHADE_BLOCK), 0, s, c->sc, b, c->dFc, pr.st, c->dQueue[pr.iter & 1], c->dQueue[(pr.iter + 1) & 1], pr.iter, (int)pr.launched, c->dCtl
             // kernel variant: transmissive materials present / statistics on / RAYTRACING == 0 / texture-mapped materials present
+            // (T: index-stack encoding of the path state — 0 no transmissive material, 3 / 8 bits per slot)
 #define SHADE_V(T, S, D, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
 #define SHADE_F(T, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, false, false, X, true>), SHADE_ARGS))
             // (the relaxed numeric contract, pt_set_option 16: path tracing without statistics only; everything else keeps the exact kernels)
 #define SHADE_S(T, D, X) do { if (c->countStats) SHADE_V(T, true, D, X); else if (fastNow && !(D)) SHADE_F(T, X); else SHADE_V(T, false, D, X); } while (0)
 #define SHADE_X(T, D) do { if (c->anyMaps) SHADE_S(T, D, true); else SHADE_S(T, D, false); } while (0)
-            if (direct) SHADE_X(false, true);
-            else if (c->trans) SHADE_X(true, false);
-            else SHADE_X(false, false);
+            if (direct) SHADE_X(0, true);
+            else if (c->niBits == 3) SHADE_X(3, false);
+            else if (c->niBits == 8) SHADE_X(8, false);
+            else SHADE_X(0, false);
             c->iter = (c->iter + 1) & 0x3fffffff;
             iters++;
         }
@@ -1495,7 +1540,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     }
     if ((int)P[2] != c->W || (int)(P[2] * P[3]) != c->H) return fail(PT_ERR_ARG, "Parameters.resolution / screenHratio do not match the FRAME image size given to pt_create");
     // the loop bounds are floats in the shader (frag.glsl:820, :898); the slot's counters have 12 bits each
-    if (!(P[4] >= 1.0f) || P[4] > 4095.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,4095]");
+    if (!(P[4] >= 1.0f) || P[4] > 2047.0f) return fail(PT_ERR_ARG, "SAMPLE_RES must be in [1,2047]");
     if (!(P[5] > 0.0f) || P[5] > 4095.0f) return fail(PT_ERR_ARG, "MAX_BOUNCES must be in (0,4095]");
     size_t nJobs64 = (size_t)c->nLocal * (size_t)nFrames;
     if (nJobs64 >= (1ull << 31)) return fail(PT_ERR_ARG, "batch too large: pixels * frames must stay below 2^31 (split the batch)");
@@ -1574,8 +1619,11 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     const int N = c->poolActive;
 #define REVIVE(T, F) TIMED_LAUNCH(2, hipLaunchKernelGGL((k_revive<T, F>), dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, b, c->dFc, c->st, N, c->dCtl))
     const bool fastRevive = c->streamFast && !direct && !c->countStats;
-    if (c->trans) { if (fastRevive) REVIVE(true, true); else REVIVE(true, false); }
-    else { if (fastRevive) REVIVE(false, true); else REVIVE(false, false); }
+    // (directDiffuse never touches the index stack: its k_shade variant is the one without it, and so is its path state — except that the pool of a
+    //  scene with transmissive materials has the groups allocated, which k_revive<niBits> initialises)
+    if (c->niBits == 3) { if (fastRevive) REVIVE(3, true); else REVIVE(3, false); }
+    else if (c->niBits == 8) { if (fastRevive) REVIVE(8, true); else REVIVE(8, false); }
+    else { if (fastRevive) REVIVE(0, true); else REVIVE(0, false); }
 #undef REVIVE
     c->streamFrames += (unsigned)nFrames; c->streamJobs += (unsigned)nJobs64;
     c->lastSubmitJobs = nJobs64; c->jobsThisImage += nJobs64;
@@ -1739,8 +1787,8 @@ int pt_destroy(pt_ctx* c) {
     flushStream(c);
     hipStreamSynchronize(c->stream);
     for (hipModule_t m : c->asmModule) if (m) hipModuleUnload(m);
-    void* ptrs[] = {c->dNodes80, c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
-                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.S1, c->st.S2, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
+    void* ptrs[] = {c->dNiTable, c->st.J, c->dNodes80, c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
+                    c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->hCtl) hipHostFree(c->hCtl);
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
@@ -2069,6 +2117,8 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 3: if (value < 1 || value > 64) return fail(PT_ERR_ARG, "next-object threshold must be in [1,64]"); c->noneMin = (int)value; c->noneMinSet = true; return PT_OK;
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
+        case 19: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "node records of the hand-written kernel: -1 automatic, 0 80-B sign-ordered, 1 64-B"); c->asmNodeLayout = (int)value; c->sceneDirty = true; return PT_OK;
+        case 18: c->forceNiBits8 = value != 0; c->sceneDirty = true; return PT_OK;
         case 17: if (value != 0 && value != 256 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)

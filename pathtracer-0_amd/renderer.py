@@ -19,7 +19,7 @@ COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "i
 KERNELS = {"extend": 0, "shade": 1, "generate": 2, "accumulate": 3}
 OPTIONS = {"path_slots": 0, "count_stats": 1, "lds_budget": 2, "none_min": 3, "extend_mode": 4, "extend_tpb": 5, "extend_cache_bytes": 6,
            "refill_min": 7, "extend_blocks_per_cu": 8, "inner_keep_eighths": 9, "bfs_nodes": 10, "stack_mode": 11,
-           "query_asm_eligible": 12, "query_asm_launches_above": 13, "asm_loop": 14, "numeric_contract": 16, "asm_tpb": 17}
+           "query_asm_eligible": 12, "query_asm_launches_above": 13, "asm_loop": 14, "numeric_contract": 16, "asm_tpb": 17, "index_stack_8bit": 18, "asm_node_layout": 19}
 
 
 def hip_runtimes_mapped():
@@ -290,7 +290,7 @@ class Renderer:
     # --- parity probes --------------------------------------------------------------------------
     def debug_math(self, fn, x, y=None):
         # rng_state / rng_result / rng_random: one NextRandom / random() call of frag.glsl:686-694, the uint32 state travels as float bits
-        names = {"sin": 0, "cos": 1, "log": 2, "exp": 3, "atan2": 4, "asin": 5, "rng_state": 6, "rng_result": 7, "rng_random": 8}
+        names = {"sin": 0, "cos": 1, "log": 2, "exp": 3, "atan2": 4, "asin": 5, "rng_state": 6, "rng_result": 7, "rng_random": 8, "unorm8": 9}
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.empty_like(x)
         yp = None if y is None else np.ascontiguousarray(y, dtype=np.float32).ctypes.data

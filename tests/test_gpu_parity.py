@@ -95,6 +95,15 @@ def test_k1_rng_vectors_on_the_device(renderer_mod):
     r.close()
 
 
+def test_unorm8_on_the_device(renderer_mod):
+    """byte / 255.0f as the texture samplers evaluate it (reciprocal + one Newton step, pt_device.hpp unorm8) against the IEEE quotient, all 256 bytes"""
+    b = np.arange(256, dtype=np.float32)
+    r = renderer_mod.Renderer(32, 32)
+    got = r.debug_math("unorm8", b)
+    r.close()
+    assert np.array_equal(got.view(np.uint32), (b / np.float32(255.0)).view(np.uint32))
+
+
 def asm_taken(r):
     """does this context's scene run on the hand-written intersect kernel (pt_extend_gfx950.s)?"""
     try:
@@ -116,12 +125,11 @@ def test_intersect_parity(pt, oracle, renderer_mod, name, W, H, mode):
     d[:4] = [[1, 0, 0], [0, -1, 0], [0, 0, 1], [0, 0, 0]]
     r = renderer_mod.Renderer(W, H)
     r.load_workload(wl)
-    r.set_option("extend_mode", mode)          # 0: one block per 256 rays; 1: persistent, compiled; 2: persistent, hand-written (C1 has ellipsoids: compiled)
+    r.set_option("extend_mode", mode)          # 0: one block per 256 rays; 1: persistent, compiled; 2: persistent, hand-written
     tuv, prim = r.debug_intersect(o, d)
     if mode == 2:
-        assert asm_taken(r) == (name != "C1")
-        if name != "C1":
-            r.set_option("query_asm_launches_above", 0)
+        assert asm_taken(r)
+        r.set_option("query_asm_launches_above", 0)
     r.close()
     sc = oracle.Scene.from_workload(wl)
     for i in range(n):
@@ -209,6 +217,15 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
     o = (np.array(wl.buffers[0]) + rs.normal(scale=0.4, size=(n, 3))).astype(np.float32)
     d = rs.normal(size=(n, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
+    e = np.asarray(wl.buffers[7]); ne = int(e[0])
+    if ne:                                                 # a quarter of the rays start in or near an ellipsoid (inside: the negative near root), half of those aim at one
+        c = e[1:1 + 3 * ne].reshape(ne, 3); rad = e[1 + 9 * ne:1 + 10 * ne]
+        k = np.arange(0, n, 4)
+        which = rs.randint(0, ne, size=k.size)
+        o[k] = (c[which] + rs.normal(size=(k.size, 3)) * rad[which, None] * rs.choice([0.3, 1.0, 2.5], size=(k.size, 1))).astype(np.float32)
+        k2 = np.arange(1, n, 8)
+        to = c[rs.randint(0, ne, size=k2.size)] + rs.normal(scale=0.05, size=(k2.size, 3)) - o[k2]
+        d[k2] = (to / np.linalg.norm(to, axis=1, keepdims=True)).astype(np.float32)
     k = rs.randint(0, n, size=n // 16)                     # every wave gets a few rays with a zero / negative-zero / NaN / infinite component
     d[k, rs.randint(0, 3, size=k.size)] = rs.choice(np.array([0.0, -0.0, np.nan, np.inf, 1e-42], np.float32), size=k.size)
     k = rs.randint(0, n, size=n // 64)
@@ -222,14 +239,26 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
                                               ("C5", 64, 36, {"subdiv": 2}, {"inner_keep_eighths": 0}), ("C4", 64, 36, {}, {}), ("C5", 64, 36, {}, {"stack_mode": 1}),
                                               ("C3", 96, 54, {}, {"asm_tpb": 1024}), ("C2", 96, 54, {}, {"asm_tpb": 1024}), ("C4", 64, 36, {}, {"asm_tpb": 1024}),
                                               ("C5", 64, 36, {}, {"asm_tpb": 1024, "stack_mode": 1, "asm_loop": 0}),
-                                              ("C3", 96, 54, {}, {"asm_tpb": 1024, "extend_blocks_per_cu": 4, "extend_cache_bytes": 114688, "refill_min": 1})])
+                                              ("C3", 96, 54, {}, {"asm_tpb": 1024, "extend_blocks_per_cu": 4, "extend_cache_bytes": 114688, "refill_min": 1}),
+                                              # ellipsoids (tested when the hit records leave) and more than 8 BVHs (root records in LDS, tested when a BVH's turn comes)
+                                              ("C1", 64, 64, {}, {}), ("C1", 64, 64, {}, {"asm_loop": 1, "refill_min": 1}), ("C1rot", 64, 64, {}, {"asm_tpb": 1024}),
+                                              ("C6", 64, 36, {}, {}), ("C6", 64, 36, {}, {"asm_loop": 0}), ("C6", 64, 36, {}, {"asm_tpb": 1024, "none_min": 1}),
+                                              ("C6", 64, 36, {"groups": 11, "nu": 8, "nv": 8}, {"refill_min": 64}), ("C6", 64, 36, {"groups": 9, "nu": 6, "nv": 6}, {"asm_loop": 0, "none_min": 32})])
 def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
     """pt_extend_gfx950.s against the compiled kernels on 64 K rays per scene, a sixteenth of them irregular (zero, denormal, infinite, NaN
     components: the rays that take its min/max step): every hit record bit for bit.  C4 and the last case run its 18-bit-stack form;
     asm_loop picks its main loop (0 phase-voting, 1 fused trip; automatic: fused unless the whole scene sits in the LDS tile, as C2 does);
     asm_tpb its block size (1024 threads: what a context alone on its GPU launches once a launch is large enough; the last case one block
-    per CU with a 112 KB tile)."""
-    wl = pt.scenes.build(name, W, H, **kw)
+    per CU with a 112 KB tile).  C1 / C6: ellipsoids (a quarter of the rays start in or near one; C1rot: all three rotated) and 64 / 11 / 9 BVHs."""
+    if name == "C1rot":
+        wl = pt.scenes.build("C1", W, H)
+        b = dict(wl.buffers); e = b[7].copy(); ne = int(e[0])
+        e[1 + 6 * ne: 1 + 9 * ne] = [0.3, 0.2, 0.1, -0.4, 0.0, 0.25, 0.0, 1.1, 0.0]
+        e[1 + 3 * ne: 1 + 6 * ne] = [1.0, 2.0, 0.5, 1.5, 1.0, 1.0, 0.7, 0.7, 2.0]
+        b[7] = e
+        wl = pt.scenes.Workload("C1rot", W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    else:
+        wl = pt.scenes.build(name, W, H, **kw)
     o, d = mixed_regular_and_axis_parallel_rays(wl, 1 << 16, 11)
     r = renderer_mod.Renderer(W, H)
     r.load_workload(wl)
@@ -254,7 +283,8 @@ def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W,
                                                      ("C4", 64, 36, 2, {}, {}), ("T1", 96, 54, 2, {}, {}), ("C3", 128, 72, 3, {}, {"asm_loop": 0}),
                                                      ("C2", 96, 54, 2, {}, {"asm_loop": 1, "path_slots": 1024}),
                                                      ("C3", 128, 72, 3, {}, {"asm_tpb": 1024}), ("C3", 128, 72, 3, {}, {"asm_tpb": 1024, "path_slots": 2048}),
-                                                     ("C4", 64, 36, 2, {}, {"asm_tpb": 1024}), ("C5", 64, 36, 2, {"subdiv": 2}, {"asm_tpb": 1024})])
+                                                     ("C4", 64, 36, 2, {}, {"asm_tpb": 1024}), ("C5", 64, 36, 2, {"subdiv": 2}, {"asm_tpb": 1024}),
+                                                     ("C1", 96, 96, 3, {}, {}), ("C6", 96, 54, 2, {}, {}), ("C6", 96, 54, 2, {}, {"asm_tpb": 1024, "path_slots": 2048})])
 def test_render_parity_handwritten_kernel(pt, oracle, renderer_mod, name, W, H, frames, kw, opts):
     """whole renders on the hand-written intersect kernel (statistics off: the counting variant is the compiled kernel) against the oracle,
     including the small pool that hands over to the device-packed tail queue"""
@@ -497,7 +527,8 @@ def test_full_size_c3_with_equirect_sky(pt, oracle, renderer_mod):
     lattice = a[::27, ::24, :3] / 2.0
     assert len(np.unique(np.round(lattice.reshape(-1, 3), 4), axis=0)) > 1000      # the sky really varies over the image
     # and the small-size form through the counting kernels too
-    small = pt.scenes.Workload(wl.name, 96, 54, dict(b, **{4: pt.scenes.make_params(96, 54, wl.sample_res, wl.max_bounces)}), wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    bs = dict(b); bs[4] = pt.scenes.make_params(96, 54, wl.sample_res, wl.max_bounces)
+    small = pt.scenes.Workload(wl.name, 96, 54, bs, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, small, 2)
     assert_same(got, ref, cnt, ocnt)
 
@@ -617,9 +648,9 @@ def test_full_size_c2_lattice_and_display(pt, oracle, renderer_mod):
     assert np.array_equal(disp, oracle.display(a, n, java_bytes=False))
 
 
-@pytest.mark.parametrize("name,xs,ys", [("C4", 24, 27), ("C5", 48, 54)])
+@pytest.mark.parametrize("name,xs,ys", [("C4", 24, 27), ("C5", 48, 54), ("C6", 48, 54)])
 def test_full_size_properties_c4_c5(pt, oracle, renderer_mod, name, xs, ys):
-    """BASELINE.json's full C4 (1920x1080, one 100k-triangle BVH) and C5 (3840x2160, 16 bounces) sizes: the overlapped schedule and a
+    """BASELINE.json's full C4 (1920x1080, one 100k-triangle BVH) and C5 (3840x2160, 16 bounces) sizes, and C6 (1920x1080, 64 BVHs + 3 ellipsoids): the overlapped schedule and a
     3-way tile split reproduce the synchronous image bit for bit; oracle parity on a pixel lattice"""
     cfg = pt.scenes.CONFIGS[name]
     W, H = cfg["W"], cfg["H"]
@@ -1072,10 +1103,14 @@ def _nested_shells_workload(pt, W=64, H=48, shells=11):
 
 @pytest.mark.parametrize("shells", [5, 8, 11])
 def test_nested_transmissive_shells(pt, oracle, renderer_mod, shells):
-    """index-stack slots 4-9 (the state groups S1 / S2, shifted in memory by the shading kernel) and the silent drop at ten entries"""
+    """index-stack slots 4-9 and the silent drop at ten entries, on both encodings of the stack in the path state: dictionary codes of 3 bits
+    (5 shells: 8 distinct values with 0.0 and 1.0029) and of 8 bits (8 and 11 shells; forced for 5)"""
     wl = _nested_shells_workload(pt, shells=shells)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
     assert_same(got, ref, cnt, ocnt)
+    if shells == 5:
+        got8, _, _, _ = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=1)
+        assert_same(got8, ref)
     r = renderer_mod.Renderer(wl.W, wl.H, devices=[0, 0])          # overlapped batches on the two-stream group
     seeds = seeds_for(pt, 1, 4)
     r.load_workload(wl); r.reset_frame()
@@ -1088,7 +1123,7 @@ def test_nested_transmissive_shells(pt, oracle, renderer_mod, shells):
 @pytest.mark.parametrize("seed", list(range(1, 19)))
 def test_random_scenes(pt, oracle, renderer_mod, seed):
     wl = _random_workload(pt, seed, ellipsoid_maps=seed > 12)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=seed % 2)      # both encodings of the index stack in the path state
     assert_same(got, ref, cnt, ocnt)
     direct = wl.with_params(RAYTRACING=0)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, direct, 2, extend_mode=seed % 2)

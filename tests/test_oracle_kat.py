@@ -278,3 +278,16 @@ def test_n2_direct_diffuse_known_answers(pt, oracle):
     b[4][9] = 0.0
     fr = _render(oracle, b, sky, W, H)
     assert np.allclose(fr[..., :3], np.array([51, 102, 204], np.float32) / 255, rtol=3e-7)
+
+
+def test_unorm8_reciprocal_form(tmp_path):
+    """The device converts a texel byte with b * RN(1/255) and one Newton step (two fmaf) instead of the division the oracle and the GL specification
+    write (pt_device.hpp unorm8): bit-equal to the IEEE quotient for all 256 bytes, checked here with the host's fmaf."""
+    import subprocess
+    src = tmp_path / "u.c"
+    src.write_text('#include <math.h>\n#include <stdio.h>\n#include <string.h>\nint main(void){int bad=0;const float r=0x1.010102p-8f;'
+                   'for(int b=0;b<256;b++){float fb=(float)b,d=fb/255.0f,q=fb*r,q2=fmaf(fmaf(-255.0f,q,fb),r,q);if(memcmp(&d,&q2,4))bad++;}'
+                   'float one=1.0f/255.0f;printf("%d %d\\n",bad,memcmp(&one,&r,4)!=0);return 0;}\n')
+    exe = tmp_path / "u"
+    subprocess.check_call(["gcc", "-O0", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"])
+    assert subprocess.check_output([str(exe)], text=True).split() == ["0", "0"]
