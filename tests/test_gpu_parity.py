@@ -243,6 +243,9 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
                                               # ellipsoids (tested when the hit records leave) and more than 8 BVHs (root records in LDS, tested when a BVH's turn comes)
                                               ("C1", 64, 64, {}, {}), ("C1", 64, 64, {}, {"asm_loop": 1, "refill_min": 1}), ("C1rot", 64, 64, {}, {"asm_tpb": 1024}),
                                               ("C6", 64, 36, {}, {}), ("C6", 64, 36, {}, {"asm_loop": 0}), ("C6", 64, 36, {}, {"asm_tpb": 1024, "none_min": 1}),
+                                              # node records of the other layout than the automatic choice (80-B sign-ordered for trees that fit the caches, else 64-B + the min/max step)
+                                              ("C3", 96, 54, {}, {"asm_node_layout": 1}), ("C3", 96, 54, {}, {"asm_node_layout": 1, "asm_loop": 0, "asm_tpb": 1024}), ("C4", 64, 36, {}, {"asm_node_layout": 0}),
+                                              ("C6", 64, 36, {}, {"asm_node_layout": 1}), ("C2", 96, 54, {}, {"asm_node_layout": 1}),
                                               ("C6", 64, 36, {"groups": 11, "nu": 8, "nv": 8}, {"refill_min": 64}), ("C6", 64, 36, {"groups": 9, "nu": 6, "nv": 6}, {"asm_loop": 0, "none_min": 32})])
 def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
     """pt_extend_gfx950.s against the compiled kernels on 64 K rays per scene, a sixteenth of them irregular (zero, denormal, infinite, NaN
