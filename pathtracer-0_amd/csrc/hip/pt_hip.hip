@@ -54,8 +54,8 @@ constexpr int BLOCK = 256;
 #endif
 constexpr int SHADE_BLOCK = SHADE_BLOCK_SIZE;     // threads per block of the shading kernel: one scheduler atomic per block per launch
 constexpr int TILE_W = 32, TILE_H = 8;
-// inner-node records of the hand-written intersect kernel above this many bytes (in the 80-B form) take the 64-B form: what an XCD's 4 MB L2 holds
-// beside the triangles and the path state streaming through it (measured: profiles/r04_*_node_records.txt)
+// a BVH whose inner-node records exceed this many bytes (in the 80-B form) makes the hand-written intersect kernel use the 64-B form: what an XCD's 4 MB
+// L2 holds beside the triangles and the path state streaming through it (measured: profiles/r04_d_node_record_layout.txt)
 #ifndef ASM_NODES_80B_LIMIT
 #define ASM_NODES_80B_LIMIT (2 << 20)
 #endif
@@ -1060,7 +1060,11 @@ int buildScene(pt_ctx* c) {
     // min / max.  Trees that do not fit the caches pay for those bytes on every node visit (C4: 552 B per segment, the chip at 0.61 of its HBM peak):
     // they get 64-B records — references, pad, (Lmin, Rmin | Lmax, Rmax) per axis — and the kernel's min/max step (pt_set_option 19 overrides).
     const size_t nInner = order.size();
-    const int asmStride = c->asmNodeLayout == 0 ? 80 : c->asmNodeLayout == 1 ? 64 : (nInner * 80 > (size_t)ASM_NODES_80B_LIMIT ? 64 : 80);
+    size_t largestTree = 0;                                       // inner nodes of the largest BVH
+    { std::vector<size_t> per(std::max(numObj, 1), 0); for (int n : order) per[objOf[n]]++; for (size_t v : per) largestTree = std::max(largestTree, v); }
+    // (what decides is the tree a ray walks deep into: C4's single 100 k-node tree gains 5 % from the small records, C6's 64 trees of 1.5 k nodes —
+    //  as many bytes in all — lose 2 %: profiles/r04_d_node_record_layout.txt)
+    const int asmStride = c->asmNodeLayout == 0 ? 80 : c->asmNodeLayout == 1 ? 64 : (largestTree * 80 > (size_t)ASM_NODES_80B_LIMIT ? 64 : 80);
     const int W_ = asmStride / 4;
     std::vector<float> nodes80(std::max<size_t>(nInner, 1) * W_, 0.0f);
     bool boxesOrdered = true, anyEmpty = false;
