@@ -9,11 +9,14 @@ FPS=32 bash scripts/pmc_all.sh ${1:-measure}/pmc_C3 C3 > $O/pmc_C3.log 2>&1; cp 
 FPS=16 bash scripts/pmc_all.sh ${1:-measure}/pmc_C4 C4 > $O/pmc_C4.log 2>&1; cp $O/pmc_C4/summary.json profiles/pmc_C4.json; echo "pmc C4 done"
 FPS=4 bash scripts/pmc_all.sh ${1:-measure}/pmc_C5 C5 > $O/pmc_C5.log 2>&1; cp $O/pmc_C5/summary.json profiles/pmc_C5.json; echo "pmc C5 done"
 FPS=8 bash scripts/pmc_all.sh ${1:-measure}/pmc_C2 C2 > $O/pmc_C2.log 2>&1; cp $O/pmc_C2/summary.json profiles/pmc_C2.json; echo "pmc C2 done"
+FPS=4 bash scripts/pmc_all.sh ${1:-measure}/pmc_C6 C6 > $O/pmc_C6.log 2>&1; cp $O/pmc_C6/summary.json profiles/pmc_C6.json; echo "pmc C6 done"
 # 2. the driver's command
 timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_c3.json 2> $O/bench_default_c3.err; echo "bench rc=$?"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c3_untimed_kernels.json 2>/dev/null
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --streams 1 > $O/bench_c3_one_stream.json 2>/dev/null
-for cfg in C2 C4 C5; do timeout -k 10 600 python3 bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; done
+# the other configurations, each with its parity block (HIP path vs the oracle on the frames the CPU baseline renders) and cpu_baseline: the 8-GPU configs C4 / C5 on ONE GPU,
+# C6 (64 BVHs + ellipsoids: the reference author's scene shape), C1 (BASELINE configs[0])
+for cfg in C2 C4 C5 C6 C1; do timeout -k 10 600 python3 bench.py --config $cfg --steps 3 --warmup 1 > $O/bench_$cfg.json 2> $O/bench_$cfg.err; echo "bench $cfg rc=$?"; done
 # 3. kernel trace + stats of the bench command (scripts/trace_stats.sh)
 bash scripts/trace_stats.sh ${1:-measure}
 # 4. tile-shard rehearsals (one shard of N alone on this GPU) and the multi-GPU context with two shards on this GPU
