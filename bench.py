@@ -69,6 +69,8 @@ def parse():
                     help="single-process rehearsal of ONE tile shard of a COUNT-GPU run (no collective); reports that shard's rate")
     ap.add_argument("--contract", default="exact", choices=["exact", "fast"], help="numeric contract: exact (default; framebuffers bit-identical to the oracle) or the "
                     "opt-in relaxed one (hardware rcp/rsq/sqrt/log/cos in Box-Muller, normalize, 1/d, 1/det; per-pixel RMSE <= 1e-3, reported in the line)")
+    ap.add_argument("--sky", type=int, nargs=2, metavar=("W", "H"), default=None, help="replace the workload's 1x1 sky texel by a synthetic W x H equirect image (the reference binds a "
+                    "4096 x 2048 one as texture 0, dispatch.java:221) and move the camera back so that a third of the primary rays see it directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
     ap.add_argument("--no-alone-pass", action="store_true", help="skip the one-stream pass after the timed region (roofline.frac then has no kernel-alone figure): "
@@ -262,6 +264,9 @@ def main():
     fps = args.frames_per_step or cfg["spp"] // sample_res
     spp_step = fps * sample_res
     wl = scenes.build(args.config, W, H)
+    if args.sky:
+        wl.sky = scenes.equirect_sky(args.sky[1], args.sky[0])
+        wl.buffers[0] = np.array([0.0, 1.0, -2.6], dtype=np.float32)
 
     if multi:
         devices = [int(d) for d in args.devices.split(",")] if args.devices else [d for d in range(args.gpus) for _ in range(K)]
@@ -418,7 +423,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic", "contract": args.contract, "hip_runtime": renderer.hip_runtime_info(),
         "config": {"workload": f"{args.config}: {W}x{H}, {cfg['bounces']}-bounce, {spp_step} spp/step ({fps} frames x SAMPLE_RES {sample_res}), "
-                               f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs, tile-sharded over {shards} shard(s) on {n_gpus} GPU(s), 1 framebuffer gather per step",
+                               f"{wl.info['triangles']} triangles / {wl.info['objects']} BVHs" + (f", {args.sky[0]}x{args.sky[1]} equirect sky" if args.sky else "") + f", tile-sharded over {shards} shard(s) on {n_gpus} GPU(s), 1 framebuffer gather per step",
                    "width": W, "height": H, "max_bounces": cfg["bounces"], "spp_per_step": spp_step, "triangles": wl.info["triangles"], "multi_gpu": how},
     }
     if gloo or os.environ.get("PT_BENCH_ONE_GPU") == "1":

@@ -489,6 +489,23 @@ def c6_many_objects(W=1920, H=1080, sample_res=8, max_bounces=8, groups=64, nu=2
     return _finish("C6", sc, W, H, CORNELL_CAM, CORNELL_ROT, (0, 0, 0), sample_res, max_bounces)
 
 
+def equirect_sky(h, w, seed=9):
+    """A synthetic equirect sky image (h, w, 4) uint8 in place of the reference's thatch_chapel_4k.png (dispatch.java:221, not in the repository): smooth
+    gradients + seeded noise + a small "sun", every texel different from its neighbours, so that the bilinear REPEAT sampler (frag.glsl:235-242) is
+    exercised on every miss."""
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.float64)
+    img[..., 0] = 90 + 80 * np.sin(2 * np.pi * x / w) + 40 * y / h
+    img[..., 1] = 110 + 60 * np.cos(4 * np.pi * x / w) * (1 - y / h)
+    img[..., 2] = 200 - 120 * y / h
+    img[..., :3] += rs.uniform(-12, 12, size=(h, w, 3))
+    sun = (x - 0.3 * w) ** 2 + (y - 0.25 * h) ** 2 < (0.02 * w) ** 2
+    img[sun, :3] = 255
+    img[..., 3] = 255
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
 BUILDERS = {"C1": c1_spheres, "C2": c2_cornell, "C3": c3_glass_metal, "C4": c4_mesh, "C5": c5_clearcoat_sss, "C6": c6_many_objects}
 
 

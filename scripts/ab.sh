@@ -10,7 +10,7 @@ shift $((OPTIND-1))
 cd $R
 if [ $PARITY = 1 ]; then
   last=${@: -1}
-  PT_HIP_LIB=$R/build/ab/$last.so timeout -k 10 400 python3 -m pytest tests/test_gpu_parity.py -x -q -k "render_parity or random_scenes or n2_direct or intersect_parity or nan_slab" 2>&1 | tail -1 || exit 1
+  PT_HIP_LIB=$R/build/ab/$last.so timeout -k 10 400 python3 -m pytest tests/test_gpu_parity.py -x -q -k "render_parity or random_scenes or n2_direct or intersect_parity or nan_slab or equals_compiled" 2>&1 | tail -1 || exit 1
 fi
 NR=""; [ $TIMES = 0 ] && NR="--no-roofline"
 for round in $(seq 1 $ROUNDS); do for cfg in $CFGS; do for lib in "$@"; do

@@ -461,6 +461,28 @@ def test_errors_surface(pt, renderer_mod):
     with pytest.raises(renderer_mod.PtError) as e:
         r.render(1, 1)
     assert e.value.code == -4
+    # the limits of the slot encoding surface as errors, not as wrong images: SAMPLE_RES beyond the 11-bit counter, and more distinct refraction
+    # indices than the index-stack dictionary holds in a scene with a transmissive material (the same scene without one renders: the stack is unobservable)
+    r.set_buffer(3, wl.buffers[3])
+    p = wl.buffers[4].copy(); p[4] = 2048.0
+    r.set_buffer(4, p)
+    with pytest.raises(renderer_mod.PtError) as e:
+        r.render(1, 1)
+    assert e.value.code == -1 and "SAMPLE_RES" in str(e.value)
+    r.set_buffer(4, wl.buffers[4])
+    me = int(wl.buffers[14][0]); n = 300
+    mtl = np.zeros(1 + me * n, np.float32); mtl[0] = me
+    one = wl.buffers[14][1:1 + me]
+    for m in range(n):
+        mtl[1 + me * m:1 + me * (m + 1)] = one
+        mtl[me * m + 16] = 1.0 + 0.001 * m                   # Ni (dispatch.java:272-324: slot 16 of the record)
+    r.set_buffer(14, mtl)
+    r.render(1, 1)                                            # no transmissive material: any number of Ni values
+    mtl[me * 7 + 12] = 0.5                                    # Tr > 0 on one of them
+    r.set_buffer(14, mtl)
+    with pytest.raises(renderer_mod.PtError) as e:
+        r.render(2, 2)
+    assert e.value.code == -5 and "refraction indices" in str(e.value)
     r.close()
 
 
@@ -491,28 +513,13 @@ def test_sky_texture_bilinear_repeat(pt, oracle, renderer_mod):
     assert_same(got, ref, cnt, ocnt)
 
 
-def _gradient_sky(h, w, seed=9):
-    """a non-trivial equirect sky: smooth gradients + seeded noise + a small "sun", every texel different from its neighbours"""
-    rs = np.random.RandomState(seed)
-    y, x = np.mgrid[0:h, 0:w]
-    img = np.zeros((h, w, 4), np.float64)
-    img[..., 0] = 90 + 80 * np.sin(2 * np.pi * x / w) + 40 * y / h
-    img[..., 1] = 110 + 60 * np.cos(4 * np.pi * x / w) * (1 - y / h)
-    img[..., 2] = 200 - 120 * y / h
-    img[..., :3] += rs.uniform(-12, 12, size=(h, w, 3))
-    sun = (x - 0.3 * w) ** 2 + (y - 0.25 * h) ** 2 < (0.02 * w) ** 2
-    img[sun, :3] = 255
-    img[..., 3] = 255
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
-
-
 def test_full_size_c3_with_equirect_sky(pt, oracle, renderer_mod):
     """the reference binds an equirect image as texture 0 (dispatch.java:221) and reads it on every miss (frag.glsl:235-242, :877): full C3
     size with a 1024x512 sky and an open room (no ceiling light needed: the sky is the light), on the shipped kernels, against the oracle on
     a pixel lattice"""
     W, H = 1920, 1080
     wl = pt.scenes.build("C3", W, H)
-    wl.sky = _gradient_sky(512, 1024)
+    wl.sky = pt.scenes.equirect_sky(512, 1024)
     b = dict(wl.buffers)
     b[0] = np.array([0.0, 1.0, -2.6], np.float32)        # further back: a third of the primary rays pass the room and see the sky directly
     wl = pt.scenes.Workload(wl.name, W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
