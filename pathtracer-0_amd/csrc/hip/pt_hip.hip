@@ -60,6 +60,18 @@ constexpr int TILE_W = 32, TILE_H = 8;
 #define ASM_NODES_80B_LIMIT (2 << 20)
 #endif
 
+// Path-state accesses stream through the caches once per launch — hundreds of MB per launch through 4 MB of L2 per XCD — while the OTHER stream's intersect
+// kernel lives on the BVH's node and triangle lines staying there: every access of a state group (and of the per-frame colour rows) carries the non-temporal
+// hint (`nt`: C3 +1.4 %, C4 +0.8 %, C5 +2.3 % with the hit-record stores of pt_extend_gfx950.s hinted too; profiles/r04_v_nontemporal_state.txt)
+__device__ __forceinline__ float4 ldS(const float4* p) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stS(float4* p, float4 v) {
+    f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(p));
+}
+
 struct FrameIn { float params[12]; float origin[3]; float rotation[3]; float mouse[3]; };
 
 struct Control {            // device-resident scheduler words shared by the whole batch
@@ -155,11 +167,11 @@ __global__ void k_frame_setup(DevScene sc, const FrameIn* in, FrameConst* fc, El
 //   G5 = RAY_ENTER_LOCATION, DISTANCE_TRAVELED and S0 = index-stack codes of an 8-bit scene: scenes with transmissive materials only
 template <int STK>
 __device__ __forceinline__ void storePath(const State& st, unsigned i, const Path& p) {
-    st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
-    st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
-    st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.sc0));
-    st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f);      // (job starts only; directDiffuse reads the group for every lane)
-    st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix));
+    stS(st.G0 + i, make_float4(p.O.x, p.O.y, p.O.z, p.D.x));
+    stS(st.G1 + i, make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p))));
+    stS(st.G2 + i, make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.sc0)));
+    stS(st.G3 + i, make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f));      // (job starts only; directDiffuse reads the group for every lane)
+    stS(st.G4 + i, make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix)));
     st.J[i] = make_uint2(p.fi, p.ls);
     if (STK) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
     if (STK == 8) st.S0[i] = make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f);
@@ -553,9 +565,9 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     const unsigned i = valid ? (queue ? queue[q] : q) : 0u;
     float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, g5 = g0;
     if (valid) {
-        g1 = st.G1[i]; g0 = st.G0[i]; h = st.H[i]; g2 = st.G2[i]; g4 = st.G4[i];
-        if (STK == 8) s0 = st.S0[i];
-        if (DIRECT) g3 = st.G3[i];
+        g1 = ldS(st.G1 + i); g0 = ldS(st.G0 + i); h = ldS(st.H + i); g2 = ldS(st.G2 + i); g4 = ldS(st.G4 + i);
+        if (STK == 8) s0 = ldS(st.S0 + i);
+        if (DIRECT) g3 = ldS(st.G3 + i);
     }
     const bool live = valid && (__float_as_uint(g1.w) & FL_ALIVE);
     Path p;
@@ -571,12 +583,12 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         // incLight of the running sample: +0.0 in every component unless the path has met an emitter and gone on (FL_INCNZ): only those lanes fetch it.
         // (directDiffuse parks its probe state in the group: that mode reads and writes it for every lane.)
         incInMemory = DIRECT || p.incNZ;
-        if (!DIRECT && p.incNZ) g3 = st.G3[i];
+        if (!DIRECT && p.incNZ) g3 = ldS(st.G3 + i);
         if (TRANS) {
             // RAY_ENTER_LOCATION / DISTANCE_TRAVELED are read only while the path is inside a medium or owes an absorption term;
             // a transmission event on any other path fetches them late (shadeSegment), which is rare
             p.g5loaded = p.inObj || p.applyAbs;
-            if (p.g5loaded) g5 = st.G5[i];
+            if (p.g5loaded) g5 = ldS(st.G5 + i);
         }
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
         p.col = v3(g2.x, g2.y, g2.z);
@@ -600,7 +612,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             } else {
                 const uint2 job = st.J[i];
                 float sr = fc.SAMPLE_RES;
-                b.colbuf[(size_t)(job.x % b.ringFrames) * b.nSlots + job.y] = make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f);   // col /= SAMPLE_RES (:915)
+                stS(b.colbuf + (size_t)(job.x % b.ringFrames) * b.nSlots + job.y, make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f));   // col /= SAMPLE_RES (:915)
                 jobDone = true;
             }
         }
@@ -654,16 +666,16 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             const bool nz = (__float_as_uint(p.inc.x) | __float_as_uint(p.inc.y) | __float_as_uint(p.inc.z)) != 0u;
             const bool changed = __float_as_uint(p.inc.x) != __float_as_uint(g3in.x) || __float_as_uint(p.inc.y) != __float_as_uint(g3in.y) ||
                                  __float_as_uint(p.inc.z) != __float_as_uint(g3in.z);
-            if (DIRECT) { if (changed) st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f); p.incNZ = false; }
-            else { if (nz && (changed || !incInMemory)) st.G3[i] = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f); p.incNZ = nz; }
+            if (DIRECT) { if (changed) stS(st.G3 + i, make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f)); p.incNZ = false; }
+            else { if (nz && (changed || !incInMemory)) stS(st.G3 + i, make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f)); p.incNZ = nz; }
         }
-        st.G0[i] = make_float4(p.O.x, p.O.y, p.O.z, p.D.x);
-        st.G1[i] = make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p)));
-        st.G2[i] = make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.sc0));
-        if (sampleDone) st.G4[i] = make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix));
+        stS(st.G0 + i, make_float4(p.O.x, p.O.y, p.O.z, p.D.x));
+        stS(st.G1 + i, make_float4(p.D.y, p.D.z, __uint_as_float(p.rng), __uint_as_float(packFlags(p))));
+        stS(st.G2 + i, make_float4(p.col.x, p.col.y, p.col.z, __uint_as_float(p.sc0)));
+        if (sampleDone) stS(st.G4 + i, make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix)));
         if (newJob) st.J[i] = make_uint2(p.fi, p.ls);
-        if (STK == 8) st.S0[i] = make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f);
-        if (TRANS) { if (p.g5dirty || newJob) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist); }
+        if (STK == 8) stS(st.S0 + i, make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f));
+        if (TRANS) { if (p.g5dirty || newJob) stS(st.G5 + i, make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist)); }
     }
     if (STATS) {                                  // statistics (count mode only): one atomic per wave
         unsigned long long lm = __ballot(live && !isProbe);      // a thickness probe is part of the same directDiffuse call
@@ -684,7 +696,7 @@ __global__ void __launch_bounds__(BLOCK) k_accumulate(Batch b, const FrameConst*
     if (inMouseOverlay(fc, gp % b.W, gp / b.W)) return;
     float4 F = frame[ls];
     for (int f = 0; f < nFrames; f++) {
-        float4 c = b.colbuf[(size_t)((f0 + (unsigned)f) % b.ringFrames) * b.nSlots + ls];
+        float4 c = ldS(b.colbuf + (size_t)((f0 + (unsigned)f) % b.ringFrames) * b.nSlots + ls);
         if ((float)(firstFrame + f) == 1.0f) F = make_float4(c.x, c.y, c.z, 1.0f);
         else F = make_float4(F.x + c.x, F.y + c.y, F.z + c.z, F.w + 1.0f);
     }
