@@ -60,3 +60,14 @@ def test_committed_bench_line_has_the_contract_keys():
 def test_bench_parses_its_flags_without_a_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_host_cores_respects_the_cgroup_quota(tmp_path, monkeypatch):
+    """bench.py's cpu_baseline uses every core the process may use: the smallest of os.cpu_count(), the affinity mask and the cgroup CPU quota"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    n, info = b.host_cores()
+    assert 1 <= n <= info["cores_available"] and n <= info.get("affinity", n)
+    if "cgroup_cpu_quota" in info:
+        assert n <= max(1, int(info["cgroup_cpu_quota"] + 0.5))
