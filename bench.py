@@ -73,8 +73,8 @@ def parse():
                     "4096 x 2048 one as texture 0, dispatch.java:221) and move the camera back so that a third of the primary rays see it directly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel HIP-event timing (events add launch gaps)")
-    ap.add_argument("--no-alone-pass", action="store_true", help="skip the one-stream pass after the timed region (roofline.frac then has no kernel-alone figure): "
-                    "for kernel traces whose per-kernel averages are to be compared with roofline.in_run")
+    ap.add_argument("--no-alone-pass", action="store_true", help="skip the one-stream pass after the timed region (the line then has no roofline.alone block): "
+                    "for kernel traces whose per-kernel averages are to be compared with roofline.avg_launch_ms")
     return ap.parse_args()
 
 
@@ -112,17 +112,18 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     """Bounds of the dominant kernel (the intersect kernel) and of the run, each recomputable from tracked files: the per-segment counter
     figures come from the committed rocprofv3 summary profiles/pmc_<config>.json (scripts/pmc_all.sh: SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU,
     FETCH_SIZE, WRITE_SIZE ... per segment), the segments per launch and the launch durations are measured live (statistics pass + HIP events
-    on the launch streams).
+    on the launch streams).  Every `frac` in the block is a fraction of a roof the hardware can actually reach, so it is <= 1.
 
-    Top level = the TIMED configuration, against the HBM roof, as SURVEY.md §8(d) / north_star define it:
-      achieved   §8(d)'s algorithmic bytes per segment of rayScene (44 B of queue traffic + 44 B per node visit + 36 B per triangle test
-                 + 124 B per hit update, the reference's buffer layout streamed from memory) x segments per launch / mean launch duration of
-                 the timed region.  The device-private BVH is served from LDS / L1 / L2, so this figure prices bytes that never reach HBM and
-                 may exceed the peak: `hbm` is the measured counterpart.
-      traffic    HBM bytes per launch from the counters (FETCH_SIZE x 2 + WRITE_SIZE, gfx950 correction), per launch like `achieved`
-      hbm        rocprofv3 bytes of BOTH kernels over the wall time of the timed region, per GPU, against the 8 TB/s peak (north_star's figure),
-                 and each kernel's own launches beside it
-      valu_issue the roof the intersect kernel sits closest to (timed configuration and alone), `alone` the kernels alone on the chip."""
+    Top level = the dominant kernel in the TIMED configuration against the resource that binds it — vector-instruction issue (its node and
+    triangle records come from LDS / L1 / L2):
+      achieved   SQ_INSTS_VALU per segment x segments per launch / mean launch duration of the timed region (HIP events on the launch streams)
+      traffic    HBM bytes per launch of that kernel from the counters (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction)
+      hbm_frac   north_star's figure: rocprofv3 HBM bytes of BOTH kernels over the wall time of the timed region, per GPU, / 8 TB/s (details under `hbm`)
+      hbm        the same against the HBM roof in the bench contract's form (bound / achieved / peak / unit / frac / traffic), and per kernel
+      algorithmic  SURVEY.md §8(d)'s bytes (44 B queue + 44 B per node visit + 36 B per triangle test + 124 B per hit update, the REFERENCE's
+                 buffer layout streamed from memory) over the same launch durations: a bookkeeping figure — the device-private BVH is served from
+                 LDS / L1 / L2, these bytes mostly never reach HBM, and for a cache-resident tree the rate exceeds the HBM peak.  No `frac`.
+      alone      the kernels alone on the chip (a one-stream pass after the timed region), shade = k_shade."""
     n_ext, ms_ext = r.kernel_time("extend")
     n_sh, ms_sh = r.kernel_time("shade")
     S = stats["segments"] / max(stats["samples"], 1)
@@ -146,50 +147,53 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     # algorithmic bytes per segment of the intersect kernel / per sample of the whole path, in the reference's layout
     b_ext = Q_EXTEND + nv * 44 + tt * 36 + hu * 124
     b_samp = S * 304 + S * (nv * 44 + tt * 36 + hu * 124) + 32.0 / sample_res
-    gbs = b_ext * seg_rate / 1e9
-    out = {"bound": "hbm", "kernel": ext_kernel, "configuration": f"the timed region: {streams} stream(s) per GPU, {n_gpus} GPU(s)",
-           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+    have_valu = bool(ke and "valu_per_segment" in ke)
+    have_hbm = bool(ke and ks and "hbm_bytes_per_segment" in ke and "hbm_bytes_per_segment" in ks)
+    ginst = ke["valu_per_segment"] * seg_rate / 1e9 if have_valu else None
+    hbm_gbs = (ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9 if have_hbm else None
+    out = {"bound": "valu_issue", "kernel": ext_kernel, "configuration": f"the timed region: {streams} stream(s) per GPU, {n_gpus} GPU(s)",
+           "achieved": round(ginst, 1) if have_valu else None, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": round(ginst / VALU_PEAK_GINST, 4) if have_valu else None,
            "traffic": round(ke["hbm_bytes_per_segment"] * seg_per_launch) if ke and "hbm_bytes_per_segment" in ke else None,
-           "algorithmic_bytes_per_segment": round(b_ext, 1), "algorithmic_bytes_per_launch": round(b_ext * seg_per_launch),
+           "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if have_hbm else None,
            "segments_per_launch": round(seg_per_launch), "avg_launch_ms": round(avg_ext, 4), "median_launch_ms": round(r.kernel_time_median("extend"), 4), "launches": n_ext,
            "extend_share_of_step": round(ms_ext / max(world, 1) / (dt * 1e3), 3), "streams_per_gpu": streams,
            "counters_stale": bool(stale), "kernel_source_hash": src_hash, "counters_from": prof_name if prof else None,
            "segments_per_sample": round(S, 3), "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3)},
-           "note": ("achieved = SURVEY.md 8(d)'s algorithmic bytes per segment (44 B queue + 44 B per node visit + 36 B per triangle test + 124 B per hit update, the reference's "
-                    "layout streamed from memory) x segments per launch / mean launch duration of the timed region (HIP events on the launch streams).  The device-private BVH is "
-                    "served from LDS / L1 / L2, so these bytes mostly never reach HBM (frac may exceed 1 for a cache-resident tree): `traffic` and `hbm` are the measured bytes.")}
-    # ---- measured HBM bytes (north_star: rocprof achieved HBM GB/s against the chip's 8 TB/s)
-    hbm = {"peak": HBM_PEAK_GBS, "unit": "GB/s", "note": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction) per segment from the committed counter summary x the segments of the "
-                                                            "timed region: both kernels over the wall time per GPU, and each kernel over its own launches"}
-    if ke and ks and "hbm_bytes_per_segment" in ke and "hbm_bytes_per_segment" in ks:
-        b = (ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
-        hbm.update({"achieved": round(b, 1), "frac": round(b / HBM_PEAK_GBS, 4), "bytes_per_segment": round(ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"], 2),
-                    "bytes_per_sample": round((ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * S + 32.0 / sample_res, 1),
+           "note": ("bound = what the dominant kernel sits under: vector-instruction issue (its records come from LDS / L1 / L2, it moves 0.06 of the HBM peak).  achieved = SQ_INSTS_VALU per "
+                    "segment (committed rocprofv3 summary) x segments per launch / mean launch duration of the timed region (HIP events on the launch streams); peak = 256 CUs x 4 SIMDs x 2.4 GHz "
+                    "/ 2 cycles per wave64 instruction.  hbm_frac = rocprofv3 HBM bytes of both kernels over the wall time / 8 TB/s (block `hbm`).  SURVEY.md 8(d)'s algorithmic bytes are under "
+                    "`algorithmic`: priced in the reference's layout, they never reach HBM for a cache-resident tree and carry no fraction.")}
+    if have_valu:
+        out.update({"valu_insts_per_segment": ke["valu_per_segment"], "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"), "wait_share": ke.get("wait_share"),
+                    "issue_stall_share": ke.get("issue_stall_share")})
+        if ks and "valu_per_segment" in ks:
+            v = (ke["valu_per_segment"] + ks["valu_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
+            out["chip_valu_issue"] = {"achieved": round(v, 1), "frac": round(v / VALU_PEAK_GINST, 4), "kernel_concurrency": round((ms_ext + ms_sh) / (dt * 1e3) / max(n_gpus, 1), 3),
+                                      "note": "both kernels' vector instructions over the wall time of the timed region, per GPU"}
+    else:
+        out["note"] = f"no counter summary in {prof_name}: run scripts/pmc_all.sh on a GPU box.  " + out["note"]
+    # ---- measured HBM bytes (north_star: rocprof achieved HBM GB/s against the chip's 8 TB/s), in the contract's form
+    hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "note": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction) per segment from the committed counter summary x the segments of the timed region: both kernels over the "
+                   "wall time per GPU; traffic = those bytes per iteration (one intersect + one shading launch); each kernel over its own launches beside it"}
+    if have_hbm:
+        bps = ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]
+        hbm.update({"achieved": round(hbm_gbs, 1), "frac": round(hbm_gbs / HBM_PEAK_GBS, 4), "traffic": round(bps * seg_per_launch), "bytes_per_segment": round(bps, 2),
+                    "bytes_per_sample": round(bps * S + 32.0 / sample_res, 1),
                     "algorithmic_queue_bytes_per_sample": round(S * 304 + 32.0 / sample_res, 1),
                     ext_kernel: {"bytes_per_segment": ke["hbm_bytes_per_segment"], "achieved": round(ke["hbm_bytes_per_segment"] * seg_rate / 1e9, 1),
                                  "frac": round(ke["hbm_bytes_per_segment"] * seg_rate / 1e9 / HBM_PEAK_GBS, 4)},
                     "k_shade": {"bytes_per_segment": ks["hbm_bytes_per_segment"], "achieved": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9, 1),
                                 "frac": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4)}})
     else:
-        hbm.update({"achieved": None, "frac": None, "note": f"no counter summary in {prof_name}: run scripts/pmc_all.sh on a GPU box"})
+        hbm.update({"achieved": None, "frac": None, "traffic": None, "note": f"no counter summary in {prof_name}: run scripts/pmc_all.sh on a GPU box"})
     out["hbm"] = hbm
-    # ---- the intersect kernel against VALU issue (the roof it sits closest to)
-    vi = {"peak": VALU_PEAK_GINST, "unit": "Ginst/s", "note": "SQ_INSTS_VALU per segment (committed rocprofv3 summary) x segments per launch / mean launch time; peak = 256 CUs x 4 SIMDs x "
-                                                               "2.4 GHz / 2 cycles per wave64 instruction; lane_util = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES"}
-    if ke and "valu_per_segment" in ke:
-        vps = ke["valu_per_segment"]
-        vi.update({"valu_insts_per_segment": vps, "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"), "wait_share": ke.get("wait_share"),
-                   "issue_stall_share": ke.get("issue_stall_share"), "achieved": round(vps * seg_rate / 1e9, 1), "frac": round(vps * seg_rate / 1e9 / VALU_PEAK_GINST, 4)})
-        if ks and "valu_per_segment" in ks:
-            v = (vps + ks["valu_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
-            vi["chip"] = {"achieved": round(v, 1), "frac": round(v / VALU_PEAK_GINST, 4), "kernel_concurrency": round((ms_ext + ms_sh) / (dt * 1e3) / max(n_gpus, 1), 3)}
-    out["valu_issue"] = vi
     # ---- the kernels ALONE on the chip (a one-stream pass after the timed region)
     if alone and alone["avg_ext_ms"] > 0:
         rate = alone["seg_per_launch"] / (alone["avg_ext_ms"] * 1e-3)
         al = {"measured_in": alone["from"], "avg_launch_ms": round(alone["avg_ext_ms"], 4), "segments_per_launch": round(alone["seg_per_launch"]), "launches": alone["launches"],
-              "algorithmic": {"achieved": round(b_ext * rate / 1e9, 1), "frac": round(b_ext * rate / 1e9 / HBM_PEAK_GBS, 4)}}
-        if ke and "valu_per_segment" in ke:
+              "algorithmic_GBps": round(b_ext * rate / 1e9, 1)}
+        if have_valu:
             al["valu_issue"] = {"achieved": round(ke["valu_per_segment"] * rate / 1e9, 1), "frac": round(ke["valu_per_segment"] * rate / 1e9 / VALU_PEAK_GINST, 4)}
         if ke and "hbm_bytes_per_segment" in ke:
             al["hbm"] = {"achieved": round(ke["hbm_bytes_per_segment"] * rate / 1e9, 1), "frac": round(ke["hbm_bytes_per_segment"] * rate / 1e9 / HBM_PEAK_GBS, 4)}
@@ -202,15 +206,18 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
             al["counters_note"] = alone["counters_note"]
         out["alone"] = al
     sh = {"kernel": "k_shade", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": round(avg_sh, 4), "median_launch_ms": round(r.kernel_time_median("shade"), 4),
-          "shade_share_of_step": round(ms_sh / max(world, 1) / (dt * 1e3), 3), "algorithmic_bytes_per_segment": 260,
-          "algorithmic": {"achieved": round(260 * seg_rate_sh / 1e9, 1), "frac": round(260 * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4)}}
+          "shade_share_of_step": round(ms_sh / max(world, 1) / (dt * 1e3), 3), "algorithmic_bytes_per_segment": 260}
     if ks and "hbm_bytes_per_segment" in ks:
         sh.update({"achieved": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9, 1), "frac": round(ks["hbm_bytes_per_segment"] * seg_rate_sh / 1e9 / HBM_PEAK_GBS, 4),
                    "bytes_per_segment": ks["hbm_bytes_per_segment"], "traffic": round(ks["hbm_bytes_per_segment"] * seg / max(n_sh, 1)), "lane_util": ks.get("lane_util")})
     out["shade"] = sh
-    out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "bytes_per_sample_whole_path": round(b_samp, 1),
-                          "whole_path_GBps_per_gpu": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1), 1), "whole_path_frac": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1) / HBM_PEAK_GBS, 4),
-                          "note": "SURVEY.md 8(d): B = S*304 + S*(Nv*44 + Tt*36 + Hu*124) + 32/SAMPLE_RES per sample x samples/s per GPU; S, Nv, Tt, Hu from the statistics pass (equal to the oracle's)"}
+    out["algorithmic"] = {"bytes_per_segment_extend": round(b_ext, 1), "bytes_per_launch_extend": round(b_ext * seg_per_launch), "extend_GBps": round(b_ext * seg_rate / 1e9, 1),
+                          "extend_GBps_over_hbm_peak": round(b_ext * seg_rate / 1e9 / HBM_PEAK_GBS, 4),
+                          "bytes_per_sample_whole_path": round(b_samp, 1), "whole_path_GBps_per_gpu": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1), 1),
+                          "whole_path_GBps_over_hbm_peak": round(b_samp * value * 1e6 / 1e9 / max(n_gpus, 1) / HBM_PEAK_GBS, 4),
+                          "note": "SURVEY.md 8(d): per segment of rayScene 44 B of queue traffic + 44 B per node visit + 36 B per triangle test + 124 B per hit update; per sample B = S*304 + "
+                                  "S*(Nv*44 + Tt*36 + Hu*124) + 32/SAMPLE_RES; S, Nv, Tt, Hu from the statistics pass (equal to the oracle's).  Priced in the reference's buffer layout as if "
+                                  "streamed from memory: the device-private BVH is served from LDS / L1 / L2, so the rate is NOT a fraction of a roof and exceeds the HBM peak for a cache-resident tree."}
     return out
 
 
@@ -476,9 +483,10 @@ def main():
             alone = {"avg_ext_ms": msa / max(na, 1), "avg_shade_ms": mss / max(ns, 1), "seg_per_launch": S_ * 2.0 * len(seeds_a) * sample_res * W * H / max(na, 1), "launches": na,
                      "from": f"a one-stream pass after the timed region: 2 x {len(seeds_a)} frames of the same workload, the kernels alone on the chip",
                      "counters_note": "per-segment counter figures are those of the committed summary (two streams per GPU, 256-thread intersect blocks); alone on its GPU the intersect "
-                                      "kernel runs 1024-thread blocks, whose counters differ by about 1 % in VALU and 4 % in HBM bytes per segment (profiles/r03_m_pmc_C3_one_stream.txt)"}
+                                      "kernel runs 1024-thread blocks, whose counters differ by about 1 % in VALU and 4 % in HBM bytes per segment (measured in round 3, profiles/r03_m_pmc_C3_one_stream.txt; not re-collected for later kernels)"}
             r1.close()
         out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res, n_gpus=n_gpus, ext_kernel=ext_kernel, alone=alone)
+        out["hbm_frac"] = out["roofline"]["hbm_frac"]      # north_star's figure at the top of the line: measured HBM bytes of both kernels / wall time / 8 TB/s
 
     if rank == 0 and full is not None and hasattr(full, "cpu") and not args.rehearse_shard:
         # SURVEY.md 8(d) ends the clock at the completion of pt_read_frame; `value` ends at the gathered image in HBM (results resident, like the inputs).

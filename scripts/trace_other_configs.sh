@@ -12,7 +12,7 @@ for f in glob.glob("$O/trace_$cfg/**/*kernel_stats.csv", recursive=True):
         print(f"{n},{row['Calls']},{float(row['TotalDurationNs'])/1e6:.3f},{float(row['AverageNs'])/1e3:.2f},{float(row['Percentage']):.3f},{float(row['MinNs'])/1e3:.2f},{float(row['MaxNs'])/1e3:.2f}")
 for l in open("$O/bench_trace_$cfg.json"):
     if l.startswith("{"):
-        d=json.loads(l); r=d["roofline"]; print("bench line of the traced run:", json.dumps({k:d[k] for k in ("value","ms_per_step","steps")}), json.dumps({k:r[k] for k in ("avg_launch_ms","launches","frac")}), "shade avg", r["shade"]["avg_launch_ms"], "chip", json.dumps({"valu": r["valu_issue"]["chip"]["frac"], "hbm": r["hbm"]["frac"]}))
+        d=json.loads(l); r=d["roofline"]; print("bench line of the traced run:", json.dumps({k:d[k] for k in ("value","ms_per_step","steps")}), json.dumps({k:r[k] for k in ("avg_launch_ms","launches","frac")}), "shade avg", r["shade"]["avg_launch_ms"], "chip", json.dumps({"valu": (r.get("chip_valu_issue") or {}).get("frac"), "hbm": r["hbm"]["frac"]}))
 PY
   rm -rf $O/trace_$cfg
 done

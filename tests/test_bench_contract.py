@@ -20,7 +20,31 @@ def test_committed_bench_line_has_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    if os.path.basename(latest) >= "r04":
+    if os.path.basename(latest) >= "r05":
+        # round 5: every fraction of the line is a fraction of a roof the hardware can reach.  Top level = the dominant kernel against the resource that binds it
+        # (vector-instruction issue), `hbm_frac` (in the block and at the top of the line) = measured HBM bytes of both kernels over the wall time / 8 TB/s,
+        # `hbm` = the same in the contract's bound / achieved / peak / unit / frac / traffic form; SURVEY.md 8(d)'s algorithmic bytes sit under `algorithmic` without a fraction
+        assert r["bound"] == "valu_issue" and r["unit"] == "Ginst/s" and 0 < r["frac"] <= 1 and r["counters_stale"] is False
+        prof = json.load(open(os.path.join(ROOT, r["counters_from"])))
+        pk = prof["kernels"][r["kernel"]]
+        assert abs(pk["valu_per_segment"] - r["valu_insts_per_segment"]) < 1e-9 and 0 < r["lane_util"] <= 1
+        assert abs(r["achieved"] - r["valu_insts_per_segment"] * r["segments_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 2e-2
+        assert abs(r["traffic"] - pk["hbm_bytes_per_segment"] * r["segments_per_launch"]) / r["traffic"] < 1e-2
+        h = r["hbm"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in h, k
+        assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and 0 < h["frac"] <= 1 and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-3
+        assert r["hbm_frac"] == h["frac"] == d["hbm_frac"]
+        assert 0 < h[r["kernel"]]["frac"] <= 1 and 0 < h["k_shade"]["frac"] <= 1 and 0 < r["chip_valu_issue"]["frac"] <= 1
+        assert "measured_in" in r["alone"] and 0 < r["alone"]["valu_issue"]["frac"] <= 1 and 0 < r["alone"]["hbm"]["frac"] <= 1
+        assert r["shade"]["bound"] == "hbm" and 0 < r["shade"]["frac"] <= 1
+
+        def no_frac_key(o):                       # the algorithmic figure is bookkeeping: nothing under it may read as a roofline fraction
+            return all(k != "frac" and no_frac_key(v) for k, v in o.items()) if isinstance(o, dict) else True
+        assert no_frac_key(r["algorithmic"]) and r["algorithmic"]["extend_GBps"] > 0
+        assert d["hip_runtime"]["version"] and d["hip_runtime"]["runtimes_mapped"] == 1
+        assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["cores_available"] and d["readback"]["ms_per_image"] > 0
+    elif os.path.basename(latest) >= "r04":
         # round 4: the top level is the TIMED configuration against the HBM roof in SURVEY.md 8(d)'s terms (algorithmic bytes per launch / live launch
         # duration; priced in the reference's layout, so a cache-resident tree may exceed 1), `traffic` and `hbm` are the measured bytes (rocprofv3
         # FETCH x 2 + WRITE of both kernels over the wall time: north_star's figure), VALU issue and the kernels alone on the chip sit under their own keys

@@ -55,6 +55,47 @@ def test_two_rank_gather_reassembles_the_frame(pt, tmp_path, W, H):
     assert np.array_equal(got, full)
 
 
+def _worker_two_shards_per_rank(rank, world, port, W, H, out_path):
+    """bench.py's process-per-GPU form as the driver's scaling runs start it: every rank holds K = 2 streams = tile shards rank*K, rank*K+1 of world*K and gathers
+    ONE block of K packed accumulators (pt_gather_image of a part group); rank 0 un-tiles world*K shards (Unsharder(..., world*K, ranks=world))"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ptimport
+    pt = ptimport.load()
+    from pathtracer_0_amd import renderer, shard
+    K = 2
+    rng = np.random.default_rng(5)                                # the same synthetic image on every rank: every pixel distinct, so a misplaced slot shows
+    full = rng.random((H * W, 4), dtype=np.float32)
+    ns = renderer.shard_slots(W, H, world * K)
+    block = np.zeros((K * ns, 4), np.float32)
+    for k in range(K):
+        m = renderer.shard_map(W, H, rank * K + k, world * K)
+        assert len(m) == ns                                     # every shard padded to the same size: the collective's blocks are equal
+        block[k * ns:(k + 1) * ns][m >= 0] = full[m[m >= 0]]
+    un = shard.Unsharder(W, H, world * K, renderer.shard_map, torch.device("cpu"), ranks=world)
+    got = shard.gather_frame(torch.from_numpy(block), un, dst=0)
+    if rank == 0:
+        np.save(out_path, np.stack([got.numpy().reshape(-1, 4), full]))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H", [(8, 100, 37), (8, 1920, 1080), (2, 96, 40)])
+def test_ranks_with_two_shards_each_reassemble_the_frame(pt, tmp_path, world, W, H):
+    """world 8 x 2 streams = the 16 tile shards of the 8-GPU run (no render: the gather layout and the un-tiling, at an odd size with fewer
+    tiles than two per shard and at the headline size)"""
+    from pathtracer_0_amd import build
+    build.build_hip()
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_worker_two_shards_per_rank, args=(world, _free_port(), W, H, out), nprocs=world, join=True)
+    got, full = np.load(out)
+    assert np.array_equal(got, full)
+
+
 class _OracleRenderer:
     """Stands in for one rank's renderer in the pipeline test: same call sequence as renderer.Renderer (next_image,
     render_batch_async, finish_image) over a ring of four shard-local accumulators, the frames coming from the oracle."""
