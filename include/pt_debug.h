@@ -32,6 +32,8 @@ extern "C" {
  *      fit the 3-bit codes that ride beside the throughput; 0 (default) automatic.
  * 19 = node records of the hand-written intersect kernel: -1 automatic (default: 80-B records whose plane pairs are stored in direction-sign order while the
  *      inner nodes fit the caches, 64-B records with the min/max step for larger trees), 0 80-B, 1 64-B.
+ * 20 = per-ray cull of the object loop in the hand-written intersect kernel for scenes with more than 8 BVHs (one pass over at most 64 group boxes when a ray
+ *      starts; the objects of a group whose box the ray misses are never tested): 1 (default) on, 0 off (every group box infinite: each root box is tested in turn).
  * Queries (tests): 12 = PT_OK iff the current scene runs on the hand-written intersect kernel (else PT_ERR_UNSUPPORTED and the reason in pt_last_error),
  * 13 = PT_OK iff that kernel has been launched more than `value` times by this context. */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);

@@ -866,6 +866,7 @@ struct pt_ctx {
                                     //    (pt_extend_gfx950.s) for the scenes it takes, 1 for the others
     float* dNodes80 = nullptr;      // node records of the hand-written kernel: the two references + (min pair, max pair, min pair) per axis (80 B), or + pad + (min pair, max pair) (64 B)
     int asmNodeStride = 80, asmNodeLayout = -1;      // bytes per record as built; pt_set_option 19: -1 automatic, 0 80-B, 1 64-B
+    int asmGroupShift = 0; bool asmNoRootCull = false;      // more than 8 BVHs: log2 of the objects per group box of the per-ray cull; pt_set_option 20 switches the cull off (every group box infinite)
     void* dAsmDbg = nullptr;
     std::string asmError;           // a failed load / launch of the hand-written kernel (surfaces as PT_ERR_HIP from the render call)
     uint64_t asmLaunches = 0;
@@ -1102,6 +1103,39 @@ int buildScene(pt_ctx* c) {
         roots[o].ref = refOf(r); roots[o].pad = 0;
         // an empty root leaf would be "visited" by the reference and find nothing: it can simply never be pushed
     }
+    // More than 8 BVHs: the hand-written kernel culls the object loop (frag.glsl:563-577) per ray with ONE pass over at most 64 GROUP boxes at refill
+    // (pt_extend_gfx950.s, .Lmask_loop): group g = objects [g << s, (g + 1) << s), its box the union of their root boxes, appended to the root records.  A ray
+    // that misses a group's box misses every root box in it (boxes of subsets; IEEE subtraction and multiplication are monotone, the ray regular: finite origin,
+    // finite non-zero reciprocal direction), and a BVH whose root box the ray misses contributes nothing: rayBVH would pop the root, find neither child box hit
+    // (children lie inside the root box) and return (:468-472, :521-531) — PROVIDED the root is an inner node whose child boxes lie inside an ordered root box.
+    // A group holding a root that does not promise this (a leaf root: its triangles are tested whatever the box says, :478-520; foreign buffers whose children
+    // stick out) gets the box (-inf, +inf): never culled.  Irregular rays skip the cull in the kernel.
+    c->asmGroupShift = 0;
+    if (numObj > 8) {
+        int sft = 0;
+        while (((numObj + (1 << sft) - 1) >> sft) > 64) sft++;
+        c->asmGroupShift = sft;
+        const int nGroups = (numObj + (1 << sft) - 1) >> sft;
+        const float inf = std::numeric_limits<float>::infinity();
+        std::vector<ObjRoot> groups(64);
+        for (int g = 0; g < 64; g++) { for (int k = 0; k < 3; k++) { groups[g].bmin[k] = inf; groups[g].bmax[k] = -inf; } groups[g].ref = 0; groups[g].pad = 0; }
+        for (int o = 0; o < numObj; o++) {
+            const int r = c->objidx[1 + o]; const float* A = c->bvhdata.data() + 8 * (size_t)r;
+            bool cullable = !isLeaf(r) && !c->asmNoRootCull;
+            for (int k = 0; k < 3 && cullable; k++) {
+                if (!(A[k] <= A[3 + k])) cullable = false;                                      // ordered, no NaN
+                for (int side = 0; side < 2 && cullable; side++) {
+                    const float* Ch = c->bvhdata.data() + 8 * (size_t)childOf(r, side);
+                    if (!(Ch[k] >= A[k]) || !(Ch[3 + k] <= A[3 + k])) cullable = false;          // the child box inside the root box (NaN: not)
+                }
+            }
+            ObjRoot& G = groups[o >> sft];
+            if (!cullable) G.pad = 1;
+            for (int k = 0; k < 3; k++) { G.bmin[k] = std::min(G.bmin[k], A[k]); G.bmax[k] = std::max(G.bmax[k], A[3 + k]); }
+        }
+        for (int g = 0; g < nGroups; g++) if (groups[g].pad) { for (int k = 0; k < 3; k++) { groups[g].bmin[k] = -inf; groups[g].bmax[k] = inf; } }
+        roots.insert(roots.end(), groups.begin(), groups.end());          // at roots[numObj .. numObj + 64)
+    }
     std::vector<float4> shade(std::max<size_t>(nTris, 1) * 4);
     for (size_t t = 0; t < nTris; t++) {
         const float* T = c->tris.data() + 40 * t;
@@ -1252,8 +1286,9 @@ struct EpAsmArgs {
     unsigned divM, divS, nWaves, mode;      // mode: 1 the fused trip, 0 the phase-voting loop
     void* dbg;                      // developer builds of the assembly (-DPT_ASM_DEBUG): 32 B per wave
     const void* ellip; int numEllip, nodeStride;      // EllipRec array (rotation matrices by k_frame_setup); bytes per node record (80 or 64)
+    int groupShift, pad0;           // more than 8 BVHs: log2 of the objects per group box (the 64 group boxes follow the root records)
 };
-static_assert(sizeof(EpAsmArgs) == 136 && offsetof(EpAsmArgs, ellip) == 120, "EpAsmArgs layout is part of the assembly");
+static_assert(sizeof(EpAsmArgs) == 144 && offsetof(EpAsmArgs, ellip) == 120 && offsetof(EpAsmArgs, groupShift) == 136, "EpAsmArgs layout is part of the assembly");
 static_assert(sizeof(EllipRec) == 128 && offsetof(EllipRec, rotated) == 32 && offsetof(EllipRec, R) == 48, "EllipRec layout is part of the assembly");
 #ifndef PT_EXTEND_INC
 #define PT_EXTEND_INC "pt_extend_hsaco.inc"
@@ -1291,7 +1326,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     const bool sharedGpu = c->streamsOnDevice > 1;
     const bool lazyRoots = sc.numObj > 8;                      // more than 8 BVHs: root records in LDS, tested when a BVH's turn comes (no per-lane distances)
     const size_t perLane = (lazyRoots ? 0 : (size_t)sc.numObj * 4) + (size_t)c->stackDepth * 2;      // root-box distances + traversal stack of one lane
-    const size_t rootBytes = lazyRoots ? (size_t)sc.numObj * 32 : 0;
+    const size_t rootBytes = lazyRoots ? ((size_t)sc.numObj + 64) * 32 : 0;      // the root records and the 64 group boxes of the per-ray cull (buildScene)
     const bool largeFits = 2 * (perLane * 1024 + rootBytes + 48 + 16384) <= (size_t)160 * 1024;      // two large blocks per CU with at least a 16 KB tile each (deep trees: stacks)
     const int TPB = c->asmTpb ? c->asmTpb : (!sharedGpu && largeFits && pr.launched >= (uint64_t)c->numCUs * 2048 ? 1024 : 256);
     const int BPW = TPB / 256;                                  // how many 256-thread blocks one block stands for
@@ -1325,7 +1360,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     if (loadAsmKernel(c, variant)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
-    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride;
+    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride; a.groupShift = c->asmGroupShift;
     a.numObj = sc.numObj; a.iter = pr.iter; a.nSlots = (int)pr.launched; a.refillMin = c->refillMin; a.keepEighths = c->innerKeepEighths; a.noneMin = c->noneMin;
     // main loop: the fused trip with fetch-at-decision, unless the whole scene sits in the LDS tile — then no fetch is worth hiding and the
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)
@@ -2135,6 +2170,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 19: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "node records of the hand-written kernel: -1 automatic, 0 80-B sign-ordered, 1 64-B"); c->asmNodeLayout = (int)value; c->sceneDirty = true; return PT_OK;
         case 18: c->forceNiBits8 = value != 0; c->sceneDirty = true; return PT_OK;
+        case 20: c->asmNoRootCull = value == 0; c->sceneDirty = true; return PT_OK;
         case 17: if (value != 0 && value != 256 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)

@@ -246,7 +246,11 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
                                               # node records of the other layout than the automatic choice (80-B sign-ordered for trees that fit the caches, else 64-B + the min/max step)
                                               ("C3", 96, 54, {}, {"asm_node_layout": 1}), ("C3", 96, 54, {}, {"asm_node_layout": 1, "asm_loop": 0, "asm_tpb": 1024}), ("C4", 64, 36, {}, {"asm_node_layout": 0}),
                                               ("C6", 64, 36, {}, {"asm_node_layout": 1}), ("C2", 96, 54, {}, {"asm_node_layout": 1}),
-                                              ("C6", 64, 36, {"groups": 11, "nu": 8, "nv": 8}, {"refill_min": 64}), ("C6", 64, 36, {"groups": 9, "nu": 6, "nv": 6}, {"asm_loop": 0, "none_min": 32})])
+                                              ("C6", 64, 36, {"groups": 11, "nu": 8, "nv": 8}, {"refill_min": 64}), ("C6", 64, 36, {"groups": 9, "nu": 6, "nv": 6}, {"asm_loop": 0, "none_min": 32}),
+                                              # the per-ray cull of the object loop (round 5): off; more BVHs than mask bits — groups of 2, 4 and 16 BVHs per bit
+                                              ("C6", 64, 36, {}, {"asm_root_cull": 0}), ("C6", 64, 36, {"groups": 70, "nu": 6, "nv": 6}, {}),
+                                              ("C6", 64, 36, {"groups": 130, "nu": 4, "nv": 4}, {"asm_loop": 0, "refill_min": 1}), ("C6", 64, 36, {"groups": 600, "nu": 4, "nv": 4}, {"asm_tpb": 1024}),
+                                              ("C6", 64, 36, {"groups": 65, "nu": 4, "nv": 4}, {"asm_node_layout": 1, "none_min": 1})])
 def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
     """pt_extend_gfx950.s against the compiled kernels on 64 K rays per scene, a sixteenth of them irregular (zero, denormal, infinite, NaN
     components: the rays that take its min/max step): every hit record bit for bit.  C4 and the last case run its 18-bit-stack form;
@@ -281,13 +285,52 @@ def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W,
     assert (out[2][1] >= 0).sum() > 1000
 
 
+@pytest.mark.parametrize("perturb", ["children_stick_out", "root_box_shrunk_to_nothing", "inverted_root_box"])
+def test_root_cull_only_where_the_boxes_promise_it(pt, renderer_mod, perturb):
+    """The per-ray cull of the object loop skips a BVH whose ROOT box the ray misses; that is rayBVH's own result only if the root's child boxes lie inside an
+    ordered root box (the reference's builder guarantees it, the C ABI takes any buffer).  Root boxes made smaller than their children, shrunk to a point far
+    away, or inverted: the hand-written kernel must still equal the compiled kernels (which test every root box in turn) bit for bit."""
+    W, H = 64, 36
+    wl = pt.scenes.build("C6", W, H, groups=24, nu=6, nv=6)
+    b = dict(wl.buffers)
+    data = np.array(b[10], dtype=np.float32).copy().reshape(-1, 8)
+    roots = np.asarray(b[13])[1:1 + int(b[13][0])]
+    for k, r in enumerate(roots[2::3]):                       # every third torus
+        lo, hi = data[r, 0:3].copy(), data[r, 3:6].copy()
+        if perturb == "children_stick_out":
+            mid = 0.5 * (lo + hi); data[r, 0:3] = mid - 0.25 * (hi - lo); data[r, 3:6] = mid + 0.25 * (hi - lo)
+        elif perturb == "root_box_shrunk_to_nothing":
+            data[r, 0:3] = 50.0 + k; data[r, 3:6] = 50.0 + k
+        else:
+            data[r, 0:3] = hi; data[r, 3:6] = lo
+    b[10] = data.reshape(-1)
+    wl = pt.scenes.Workload("C6p", W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    o, d = mixed_regular_and_axis_parallel_rays(wl, 1 << 16, 12)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl)
+    if perturb == "inverted_root_box":
+        r.set_option("asm_node_layout", 1)                    # (an inverted box is what the 80-B sign-ordered records cannot hold: such scenes run the compiled kernel; the 64-B layout's min/max step takes them)
+    assert asm_taken(r)
+    out = {}
+    for mode in (2, 1):
+        r.set_option("extend_mode", mode)
+        tuv, prim = r.debug_intersect(o, d)
+        out[mode] = (tuv.view(np.uint32).copy(), prim.copy())
+    r.set_option("query_asm_launches_above", 0)
+    r.close()
+    same = (out[2][1] == out[1][1]) & (out[2][0] == out[1][0]).all(axis=1)
+    assert same.all(), (int((~same).sum()), np.nonzero(~same)[0][:8])
+    assert (out[2][1] >= 0).sum() > 1000
+
+
 @pytest.mark.parametrize("name,W,H,frames,kw,opts", [("C2", 96, 54, 3, {}, {}), ("C3", 128, 72, 3, {}, {}), ("C3", 128, 72, 4, {}, {"path_slots": 2048}),
                                                      ("C3", 128, 72, 2, {}, {"path_slots": 1 << 16, "refill_min": 8}), ("C5", 64, 36, 2, {"subdiv": 2}, {}),
                                                      ("C4", 64, 36, 2, {}, {}), ("T1", 96, 54, 2, {}, {}), ("C3", 128, 72, 3, {}, {"asm_loop": 0}),
                                                      ("C2", 96, 54, 2, {}, {"asm_loop": 1, "path_slots": 1024}),
                                                      ("C3", 128, 72, 3, {}, {"asm_tpb": 1024}), ("C3", 128, 72, 3, {}, {"asm_tpb": 1024, "path_slots": 2048}),
                                                      ("C4", 64, 36, 2, {}, {"asm_tpb": 1024}), ("C5", 64, 36, 2, {"subdiv": 2}, {"asm_tpb": 1024}),
-                                                     ("C1", 96, 96, 3, {}, {}), ("C6", 96, 54, 2, {}, {}), ("C6", 96, 54, 2, {}, {"asm_tpb": 1024, "path_slots": 2048})])
+                                                     ("C1", 96, 96, 3, {}, {}), ("C6", 96, 54, 2, {}, {}), ("C6", 96, 54, 2, {}, {"asm_tpb": 1024, "path_slots": 2048}),
+                                                     ("C6", 96, 54, 2, {"groups": 70, "nu": 6, "nv": 6}, {}), ("C6", 96, 54, 2, {"groups": 200, "nu": 4, "nv": 4}, {"path_slots": 2048})])
 def test_render_parity_handwritten_kernel(pt, oracle, renderer_mod, name, W, H, frames, kw, opts):
     """whole renders on the hand-written intersect kernel (statistics off: the counting variant is the compiled kernel) against the oracle,
     including the small pool that hands over to the device-packed tail queue"""
