@@ -52,7 +52,9 @@ struct orc_scene {
 };
 
 // counters: S, Nv, Tt, Hu + extras
-enum { C_SEGMENTS = 0, C_NODES, C_TRITESTS, C_HITUPD, C_SAMPLES, C_BOXTESTS, C_RNG, C_ELLIP, C_N };
+// ... and the shape of the traversal (what a kernel that takes two steps per trip could chain): inner nodes popped; those popped right after their
+// parent's step as its left / its right child (the near child, pushed last); leaves popped right after their parent's step, and those of them that hold one triangle
+enum { C_SEGMENTS = 0, C_NODES, C_TRITESTS, C_HITUPD, C_SAMPLES, C_BOXTESTS, C_RNG, C_ELLIP, C_INNER, C_LEFTNEXT, C_RIGHTNEXT, C_LEAFNEXT, C_LEAFNEXT1, C_N };
 
 }  // extern "C"
 
@@ -263,11 +265,23 @@ BvhResult rayBVH(Ctx& c, vec3 o, vec3 d, int top, float previous_closest_t) {
     if (c.count) c.cnt[C_BOXTESTS]++;
     if (rayBox(o, invD, s->bvhdata + 8 * top) > closest_t) return res;
     stack[sp++] = top;
+    int prevInner = -1;                          // (statistics only) the inner node of the previous iteration, -1 after a leaf
     while (sp > 0) {
         int node = stack[--sp];
         if (c.count) c.cnt[C_NODES]++;
         int left = s->bvhtree[3 * node + 1], right = s->bvhtree[3 * node + 2];
         bool isLeaf = (left | right) == -1;
+        if (c.count) {
+            const bool fromParent = prevInner >= 0 && (node == s->bvhtree[3 * prevInner + 1] || node == s->bvhtree[3 * prevInner + 2]);
+            if (!isLeaf) {
+                c.cnt[C_INNER]++;
+                if (fromParent) c.cnt[node == s->bvhtree[3 * prevInner + 1] ? C_LEFTNEXT : C_RIGHTNEXT]++;
+            } else if (fromParent) {
+                c.cnt[C_LEAFNEXT]++;
+                if ((int)s->bvhdata[8 * node + 7] - (int)s->bvhdata[8 * node + 6] == 1) c.cnt[C_LEAFNEXT1]++;
+            }
+            prevInner = isLeaf ? -1 : node;
+        }
         if (isLeaf) {
             int startIdx = (int)s->bvhdata[8 * node + 6], endIdx = (int)s->bvhdata[8 * node + 7];
             for (int i = startIdx; i < endIdx; i++) {

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "rng", "ellip"]
+COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "rng", "ellip", "inner", "leftnext", "rightnext", "leafnext", "leafnext1"]
 
 
 class _Scene(C.Structure):

@@ -290,6 +290,15 @@ PM_DEV vec3 randLambertianDistVec(uint32_t& st) {
     float x = randValNormalDist<FAST>(st), y = randValNormalDist<FAST>(st), z = randValNormalDist<FAST>(st);
     return v3(x, y, z);
 }
+// The six draws of randLambertianDistVec when nobody reads the vector (chooseRay draws it before trace() finds the bounce budget used up or the path cut off,
+// :775-804 then :866 / :820; the sample loop's next iteration goes on with the advanced rngState, :898-908): six steps of NextRandom's LCG in one
+constexpr uint32_t lcgPow(uint32_t a, int n) { return n == 0 ? 1u : a * lcgPow(a, n - 1); }
+constexpr uint32_t lcgSum(uint32_t a, uint32_t c, int n) { return n == 0 ? 0u : lcgSum(a, c, n - 1) * a + c; }
+PM_DEV uint32_t skipSixDraws(uint32_t state) {
+    constexpr uint32_t A6 = lcgPow(747796405u, 6), C6 = lcgSum(747796405u, 2891336453u, 6);
+    static_assert(A6 == 1226092713u && C6 == 3109587930u, "six steps of state * 747796405 + 2891336453 (mod 2^32)");
+    return state * A6 + C6;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Path state of one lane (registers); stored SoA in groups of float4 (see pt_hip.hip)
@@ -506,16 +515,21 @@ PM_DEV vec3 lobeDirection(int w, vec3 G, vec3 N, vec3 D, float eta, float Pcr) {
 }
 
 // Camera ray of one sample, main() frag.glsl:894-908, for global pixel (px,py): lens jitter (6 RNG draws), focus, normalise.
+// (G = the Gaussian vector of the lens jitter, drawn by the caller: the shading kernel has ONE site of randLambertianDistVec for lobes and lenses)
 template <bool FAST = false>
-PM_DEV void cameraRay(const FrameConst& fc, int W, int H, int px, int py, uint32_t& rng, vec3& O, vec3& D) {
+PM_DEV void cameraRayFrom(const FrameConst& fc, int W, int H, int px, int py, vec3 G, vec3& O, vec3& D) {
     float tcx = ((float)px + 0.5f) / (float)W, tcy = ((float)py + 0.5f) / (float)H;
     vec3 q = v3(((tcx * 2.0f - 1.0f) * -1.0f) * fc.screenSize, ((tcy * 2.0f - 1.0f) * fc.screenHratio) * fc.screenSize, fc.focalLength);
     vec3 direction = vecmat(q, fc.camRot);
     vec3 ORIGIN = v3(fc.origin[0], fc.origin[1], fc.origin[2]);
-    vec3 origin_jittered = ORIGIN + vecmat(randLambertianDistVec<FAST>(rng) * fc.BLUR, fc.camRot);
+    vec3 origin_jittered = ORIGIN + vecmat(G * fc.BLUR, fc.camRot);
     vec3 focal_point = ORIGIN + direction * fc.focus;
     D = normalizeT<FAST>(focal_point - origin_jittered);
     O = origin_jittered;
+}
+template <bool FAST = false>
+PM_DEV void cameraRay(const FrameConst& fc, int W, int H, int px, int py, uint32_t& rng, vec3& O, vec3& D) {
+    cameraRayFrom<FAST>(fc, W, H, px, py, randLambertianDistVec<FAST>(rng), O, D);
 }
 // trace() prologue (:811-818): everything a new sample resets that needs no random numbers
 template <int STK> PM_DEV void tracePrologue(Path& p) {
@@ -545,13 +559,26 @@ PM_DEV bool inMouseOverlay(const FrameConst& fc, int px, int py) {          // :
     return __builtin_fabsf((float)px - fc.mouse[0]) < fc.resolution * 0.005f && __builtin_fabsf((float)py - fc.mouse[1]) < fc.resolution * 0.005f;
 }
 
-// One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879).
-// Returns true when the sample is finished (miss, cut-off, or bounce budget used up).
+// Whether this iteration of trace()'s loop ends the sample (miss :876-878, cut-off :866, bounce budget :820) follows from the path state and the hit record alone —
+// the shading kernel asks before it shades, so that its job pull and the loads only a finished sample needs are under way while it does.
+PM_DEV bool segmentHit(float ht, int prim) { return !(prim == PRIM_NONE || !(ht < 1e25f)); }     // hit.id > -1 (:823) / closest_t < 1e25 (:634)
+template <bool FAST = false>
+PM_DEV bool segmentEndsSample(const FrameConst& fc, const Path& p, float ht, int prim) {
+    return !segmentHit(ht, prim) || lengthT<FAST>(p.col) < 0.1f || !((float)(p.bounce + 1) < fc.MAX_BOUNCES);
+}
+// The lobe of a surface hit whose out direction still waits for its Gaussian vector (lobeDirection): the vector is drawn at the kernel's one site of
+// randLambertianDistVec, which the lens jitter of new samples shares
+struct LobePending { vec3 N; float Pcr; int w; bool needG; };
+
+// One iteration of trace()'s while loop AFTER rayScene returned (frag.glsl:823-879), up to the Gaussian draw of chooseRay: the transmission lobe's direction is
+// set here, the others' (L.needG) by the caller — p.D = lobeDirection(L.w, G, L.N, p.D, ., L.Pcr) with G = randLambertianDistVec(p.rng) — or, when the sample
+// ends here, not at all: the six draws then only advance the stream (skipSixDraws).
+// Returns true when the sample is finished (miss, cut-off, or bounce budget used up): segmentEndsSample's answer.
 template <int STK, bool TEX, bool FAST = false>
-PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, const float4* HX, unsigned slot) {
+PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, float ht, float hu, float hv, int prim, const float4* G5, const float4* HX, unsigned slot, LobePending& L) {
     constexpr bool TRANS = STK != 0;
     p.bounce++;                                               // :821
-    const bool hit = !(prim == PRIM_NONE || !(ht < 1e25f));   // hit.id > -1 (:823) / closest_t < 1e25 (:634)
+    const bool hit = segmentHit(ht, prim);
     const vec3 D = p.D;
     vec3 N = v3(0.0f), Ke = v3(0.0f), albedoKd = v3(0.0f), albedoKs = v3(0.0f), Tf = v3(0.0f);
     float ND = 0.0f, n1 = 1.0f, n2 = 1.0f, Pcr = 0.0f, Density = 0.0f;
@@ -593,13 +620,12 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
         Ke = v3(m.Ke[0], m.Ke[1], m.Ke[2]); albedoKd = v3(m.Kd[0], m.Kd[1], m.Kd[2]); albedoKs = v3(m.Ks[0], m.Ks[1], m.Ks[2]);
         Tf = v3(m.Tf[0], m.Tf[1], m.Tf[2]); Pcr = m.Pcr; Density = m.Density;
     }
-    vec3 G = v3(0.0f);
-    if (hit && w != 3) G = randLambertianDistVec<FAST>(p.rng);      // the single random-vector site of the shading stage
+    L.N = N; L.Pcr = Pcr; L.w = w; L.needG = hit && w != 3;
     if (!hit) {
         p.inc = p.inc + bgCol(sc, D) * p.col;                 // :877
         return true;
     }
-    p.D = lobeDirection<FAST>(w, G, N, D, divT<FAST>(n1, n2), Pcr);
+    if (w == 3) p.D = lobeDirection<FAST>(3, v3(0.0f), N, D, divT<FAST>(n1, n2), Pcr);      // :783: no random vector
     if (TRANS && w == 3) {                                    // :847-863
         if (!p.g5loaded) { float4 g5 = G5[slot]; p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5loaded = true; }   // only transmission touches it
         p.g5dirty = true;

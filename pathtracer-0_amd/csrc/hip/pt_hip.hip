@@ -564,8 +564,13 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     const bool valid = q < n;
     const unsigned i = valid ? (queue ? queue[q] : q) : 0u;
     float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, g5 = g0;
+    // Path tracing decides BEFORE it shades whether the segment ends its sample (segmentEndsSample: the hit record, the throughput and the bounce count say so):
+    // the sum over the job's samples (G4, 16 B) and the job words (J) are then fetched by the lanes whose sample / job ends only — a segment in four — and the job
+    // pull runs while those loads and the shading records are on their way.  directDiffuse learns it from the material (a subsurface hit goes on as a probe): old order.
+    constexpr bool EARLY = !DIRECT;
     if (valid) {
-        g1 = ldS(st.G1 + i); g0 = ldS(st.G0 + i); h = ldS(st.H + i); g2 = ldS(st.G2 + i); g4 = ldS(st.G4 + i);
+        g1 = ldS(st.G1 + i); g0 = ldS(st.G0 + i); h = ldS(st.H + i); g2 = ldS(st.G2 + i);
+        if (!EARLY) g4 = ldS(st.G4 + i);
         if (STK == 8) s0 = ldS(st.S0 + i);
         if (DIRECT) g3 = ldS(st.G3 + i);
     }
@@ -578,6 +583,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     // transmission lobe won; incLight (G3) when it is not zero and not what memory holds.
     bool sampleDone = false, newJob = false, isProbe = false, incInMemory = false;
     float4 g3in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint2 jobWords = make_uint2(0u, 0u);
     if (live) {
         unpackFlags(p, __float_as_uint(g1.w));
         // incLight of the running sample: +0.0 in every component unless the path has met an emitter and gone on (FL_INCNZ): only those lanes fetch it.
@@ -592,8 +598,17 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         }
         p.O = v3(g0.x, g0.y, g0.z); p.D = v3(g0.w, g1.x, g1.y); p.rng = __float_as_uint(g1.z);
         p.col = v3(g2.x, g2.y, g2.z);
+        if (EARLY) {
+            sampleDone = segmentEndsSample<FAST>(fc, p, h.x, __float_as_int(h.w));
+            if (sampleDone) {
+                g4 = ldS(st.G4 + i);
+                nSamp = 1;
+                if ((float)(p.sample + 1) < fc.SAMPLE_RES) needStart = true;      // loop condition :898
+                else { jobDone = true; jobWords = st.J[i]; }
+            }
+        }
         p.inc = incInMemory ? v3(g3.x, g3.y, g3.z) : v3(0.0f);
-        p.sum = v3(g4.x, g4.y, g4.z); p.pix = __float_as_uint(g4.w);
+        p.sum = v3(g4.x, g4.y, g4.z); p.pix = __float_as_uint(g4.w);      // (path tracing: of the lanes whose sample ends; the others neither read nor write them)
         p.fi = 0u; p.ls = 0u;                                       // the job's (frame slot, accumulator slot) wait in J until the job ends
         p.enter = v3(g5.x, g5.y, g5.z); p.dist = g5.w; p.g5dirty = false;
         if (!TRANS) p.g5loaded = true;
@@ -601,23 +616,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         if (STK == 8) { p.sc0 = __float_as_uint(s0.x); p.sc1 = __float_as_uint(s0.y); p.sc2 = __float_as_uint(s0.z); }
         else { p.sc0 = __float_as_uint(g2.w); p.sc1 = 0u; p.sc2 = 0u; }
         isProbe = DIRECT && p.probe;
-        if (DIRECT) sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w), st.HX, i);      // RAYTRACING == 0 (frag.glsl:911-912)
-        else sampleDone = shadeSegment<STK, TEX, FAST>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i);
-        if (sampleDone) {
-            p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
-            p.sample++;
-            nSamp = 1;
-            if ((float)p.sample < fc.SAMPLE_RES) {                 // loop condition :898
-                needStart = true;
-            } else {
-                const uint2 job = st.J[i];
-                float sr = fc.SAMPLE_RES;
-                stS(b.colbuf + (size_t)(job.x % b.ringFrames) * b.nSlots + job.y, make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f));   // col /= SAMPLE_RES (:915)
-                jobDone = true;
+        if (DIRECT) {
+            sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w), st.HX, i);      // RAYTRACING == 0 (frag.glsl:911-912)
+            if (sampleDone) {
+                p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
+                p.sample++;
+                nSamp = 1;
+                if ((float)p.sample < fc.SAMPLE_RES) needStart = true;      // loop condition :898
+                else { jobDone = true; jobWords = st.J[i]; }
             }
         }
     }
-    // ---- 4. job pull: ballot + prefix count per wave, aggregated over the block's 4 waves through LDS, so the
+    // ---- 2. job pull: ballot + prefix count per wave, aggregated over the block's 4 waves through LDS, so the
     // scheduler word sees ONE atomic per 256 lanes per launch (a single address sustains only ~90 atomics/us)
     unsigned long long mask = __ballot(jobDone);
     if (lane == 0) sCntA[wave] = (unsigned)__popcll(mask);
@@ -630,17 +640,18 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         if (total && sBase + total > jobEnd) ctl->exhausted[(iter + 1) & 3] = 1u;                      // an empty pull: the tail begins
     }
     __syncthreads();
+    unsigned nextJob = 0u;
+    bool gotJob = false;
     if (jobDone) {
         unsigned off = 0;
 #pragma unroll
         for (int w = 0; w < SHADE_BLOCK / 64; w++) off += (w < wave) ? sCntA[w] : 0u;
-        unsigned job = sBase + off + (unsigned)__popcll(mask & ltMask);
-        if (job < jobEnd) { startJob(b, fc, job, p); needStart = true; newJob = true; }
-        else p.alive = false;
+        nextJob = sBase + off + (unsigned)__popcll(mask & ltMask);
+        gotJob = nextJob < jobEnd;
     }
-    // ---- 4b. tail of the batch: the slots that stay alive go into the next iteration's dense queue (one atomic per block)
+    // ---- 2b. tail of the batch: the slots that stay alive go into the next iteration's dense queue (one atomic per block)
     if (writeQueue) {
-        const bool keep = live && p.alive;
+        const bool keep = live && p.alive && !(jobDone && !gotJob);
         unsigned long long mk = __ballot(keep);
         if (lane == 0) sCntB[wave] = (unsigned)__popcll(mk);
         __syncthreads();
@@ -658,8 +669,30 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
             qOut[sBase + off + (unsigned)__popcll(mk & ltMask)] = i;
         }
     }
-    // ---- 5. a lane that starts a sample computes its camera ray itself (frag.glsl:899-908); every store stays in slot order
-    if (needStart) { tracePrologue<STK>(p); cameraRay<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), p.rng, p.O, p.D); }
+    // ---- 3. the segment (frag.glsl:823-879), then what a finished sample / a finished job leaves behind
+    LobePending L; L.N = v3(0.0f); L.Pcr = 0.0f; L.w = 0; L.needG = false;
+    if (live && EARLY) {
+        shadeSegment<STK, TEX, FAST>(sc, fc, p, h.x, h.y, h.z, __float_as_int(h.w), st.G5, st.HX, i, L);      // (its answer is sampleDone's)
+        if (sampleDone) {
+            p.sum = p.sum + p.inc;                                 // col += trace(...)  (:910)
+            p.sample++;
+            // the sample loop goes on in this job's stream: chooseRay's six draws, made before trace() ended the sample, are behind it
+            if (!jobDone && L.needG) p.rng = skipSixDraws(p.rng);
+        }
+    }
+    if (jobDone) {
+        float sr = fc.SAMPLE_RES;
+        stS(b.colbuf + (size_t)(jobWords.x % b.ringFrames) * b.nSlots + jobWords.y, make_float4(p.sum.x / sr, p.sum.y / sr, p.sum.z / sr, 1.0f));   // col /= SAMPLE_RES (:915)
+        if (gotJob) { startJob(b, fc, nextJob, p); needStart = true; newJob = true; }
+        else p.alive = false;
+    }
+    // ---- 4. ONE site of randLambertianDistVec: a lane whose path goes on draws the Gaussian vector of its lobe (chooseRay, :775-804), a lane that starts a
+    // sample the one of its lens jitter (frag.glsl:899-908) — a lane is one or the other; every store stays in slot order
+    const bool drawLobe = live && !sampleDone && L.needG;
+    vec3 G = v3(0.0f);
+    if (needStart || drawLobe) G = randLambertianDistVec<FAST>(p.rng);
+    if (needStart) { tracePrologue<STK>(p); cameraRayFrom<FAST>(fc, b.W, b.H, (int)(p.pix & 0xffffu), (int)(p.pix >> 16), G, p.O, p.D); }
+    else if (drawLobe) p.D = lobeDirection<FAST>(L.w, G, L.N, p.D, 0.0f, L.Pcr);
     if (live) {
         {   // incLight leaves zero only at an emitter whose sample goes on, and returns to it with the next sample (tracePrologue): most segments
             // neither read nor write the group
@@ -1079,7 +1112,7 @@ int buildScene(pt_ctx* c) {
     //  as many bytes in all — lose 2 %: profiles/r04_d_node_record_layout.txt)
     const int asmStride = c->asmNodeLayout == 0 ? 80 : c->asmNodeLayout == 1 ? 64 : (largestTree * 80 > (size_t)ASM_NODES_80B_LIMIT ? 64 : 80);
     const int W_ = asmStride / 4;
-    std::vector<float> nodes80(std::max<size_t>(nInner, 1) * W_, 0.0f);
+    std::vector<float> nodes80(std::max<size_t>(nInner, 1) * W_ + 40, 0.0f);      // (+ 160 B: developer builds of the kernel read behind a record, -DFETCH_EXTRA)
     bool boxesOrdered = true, anyEmpty = false;
     for (size_t k = 0; k < nInner; k++) {
         const int n = order[k], L = childOf(n, 0), R = childOf(n, 1);
