@@ -89,8 +89,7 @@ int pt_reset_frame(pt_ctx* ctx);
  * On return the frame is accumulated in FRAME (in stream order on the context's stream).
  * Limits of this implementation where the shader's are its int range (PT_ERR_ARG / PT_ERR_UNSUPPORTED / PT_ERR_SCENE otherwise):
  * SAMPLE_RES <= 2047, MAX_BOUNCES <= 4095, pixels * frames of a batch < 2^31, BVH depth <= 64 (the shader's own `int stack[64]`,
- * frag.glsl:465), at most 254 distinct Ni values among the materials of a scene that has a transmissive material, texture indices
- * <= 4095, no implicit surfaces (dead code in the reference). */
+ * frag.glsl:465), texture indices <= 4095, no implicit surfaces (dead code in the reference). */
 int pt_render(pt_ctx* ctx, int frame_count, int seed);
 /* n_frames consecutive frames (u_frameCount = first_frame .. first_frame+n_frames-1, u_seed =
  * seeds[i]) rendered as ONE wavefront batch; FRAME is accumulated in frame order, so the result

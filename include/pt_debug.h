@@ -29,7 +29,8 @@ extern "C" {
  *      hardware's v_log / v_cos / v_sqrt / v_rsq / v_rcp units: results within north_star's per-pixel RMSE <= 1e-3 of the oracle, not bit-identical.
  *      Applies to path tracing (RAYTRACING == 1) without statistics; takes effect with the next frame stream.
  * 18 = index-stack encoding of the path state (tests): 1 forces 8-bit dictionary codes (a 16-B state group) where the scene's refraction indices would
- *      fit the 3-bit codes that ride beside the throughput; 0 (default) automatic.
+ *      fit the 3-bit codes that ride beside the throughput, 2 the ten floats themselves (three groups; what a scene with more than 254 distinct Ni gets);
+ *      0 (default) automatic.
  * 19 = node records of the hand-written intersect kernel: -1 automatic (default: 80-B records whose plane pairs are stored in direction-sign order while the
  *      inner nodes fit the caches, 64-B records with the min/max step for larger trees), 0 80-B, 1 64-B.
  * 20 = per-ray cull of the object loop in the hand-written intersect kernel for scenes with more than 8 BVHs (one pass over at most 64 group boxes when a ray

@@ -326,6 +326,7 @@ struct Path {
     bool inObj, applyAbs, alive, probe; int probeObj;
     vec3 enter; float dist;   // RAY_ENTER_LOCATION, DISTANCE_TRAVELED
     uint32_t sc0, sc1, sc2; // refractionIndiceStack as dictionary codes, slot 0 in the lowest bits: 3-bit codes all in sc0; 8-bit codes: slots 0-3, 4-7, 8-9
+    uint32_t sk[10];        // ... or, STK == 32 (a scene with more distinct Ni than the 8-bit dictionary holds), the ten floats themselves, as bits
     bool incNZ;            // FL_INCNZ
     bool g5loaded, g5dirty; // lazily fetched / modified (enter, dist) group, see k_shade
 };
@@ -343,11 +344,18 @@ PM_DEV void unpackFlags(Path& p, uint32_t f) {
 
 // index stack, frag.glsl:139-158.  The shader's array shifts move slots [0, size] up (addToIndiceStack, only when size < 10) or slots [1, size) down
 // (removeFirstOfIndiceStack) and leave every other slot as it was — stale values stay readable, and are read (:835, :839 with size 1).  On the packed
-// codes that is one shift of the whole word merged under a mask of the slots the loop touches.  STK: 3 or 8 bits per code.
+// codes that is one shift of the whole word merged under a mask of the slots the loop touches.  STK: 3 or 8 bits per code; 32: no codes, the floats' bits in ten registers (any number of distinct refraction indices).
+// what a material pushes (:834) / what trace()'s prologue pushes (:816): its dictionary code, or the float's bits
+template <int STK> PM_DEV uint32_t stackElemOf(const MatRec& m) { return STK == 32 ? __float_as_uint(m.Ni) : (uint32_t)m.niCode; }
+template <int STK> PM_DEV uint32_t stackElemAir() { return STK == 32 ? __float_as_uint(1.0029f) : 1u; }
 template <int STK> PM_DEV void addToIndiceStack(Path& p, uint32_t e) {
     if (p.stackSize < 10) {
         const int n = p.stackSize + 1;                           // slots 0 .. size are rewritten
-        if (STK == 3) {
+        if (STK == 32) {
+#pragma unroll
+            for (int k = 9; k >= 1; k--) p.sk[k] = (k < n) ? p.sk[k - 1] : p.sk[k];
+            p.sk[0] = e;
+        } else if (STK == 3) {
             const uint32_t m = n >= 10 ? 0x3fffffffu : ((1u << (3 * n)) - 1u);
             p.sc0 = ((((p.sc0 << 3) | e) & m) | (p.sc0 & ~m));
         } else {
@@ -364,7 +372,10 @@ template <int STK> PM_DEV void addToIndiceStack(Path& p, uint32_t e) {
 template <int STK> PM_DEV void removeFirstOfIndiceStack(Path& p) {
     if (p.stackSize > 0) {
         const int n = p.stackSize - 1;                           // slots 0 .. size-2 are rewritten
-        if (STK == 3) {
+        if (STK == 32) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) p.sk[k] = (k < n) ? p.sk[k + 1] : p.sk[k];
+        } else if (STK == 3) {
             const uint32_t m = (1u << (3 * n)) - 1u;
             p.sc0 = ((p.sc0 >> 3) & m) | (p.sc0 & ~m);
         } else {
@@ -380,6 +391,7 @@ template <int STK> PM_DEV void removeFirstOfIndiceStack(Path& p) {
 }
 // refractionIndiceStack[slot] for slot 0 or 1 (the only slots trace() reads, :835-839)
 template <int STK> PM_DEV float indiceStackSlot(const DevScene& sc, const Path& p, int slot) {
+    if (STK == 32) return __uint_as_float(p.sk[slot]);
     if (STK == 3) {
         const uint32_t c = (p.sc0 >> (3 * slot)) & 7u;
         float v = sc.ni8[0];
@@ -535,7 +547,7 @@ PM_DEV void cameraRay(const FrameConst& fc, int W, int H, int px, int py, uint32
 template <int STK> PM_DEV void tracePrologue(Path& p) {
     p.col = v3(1.0f); p.inc = v3(0.0f);
     p.stackSize = 0;                       // clearIndiceStack
-    if (STK) addToIndiceStack<STK>(p, 1u); // 1.0029 (dictionary code 1); a scene without transmissive materials never reads the stack (:753)
+    if (STK) addToIndiceStack<STK>(p, stackElemAir<STK>()); // 1.0029 (dictionary code 1, or its bits); a scene without transmissive materials never reads the stack (:753)
     else p.stackSize = 1;
     p.inObj = false;
     p.bounce = 0;
@@ -613,7 +625,7 @@ PM_DEV bool shadeSegment(const DevScene& sc, const FrameConst& fc, Path& p, floa
             const float s0 = indiceStackSlot<STK>(sc, p, 0), s1 = indiceStackSlot<STK>(sc, p, 1);
             // :833-836: slot 1 after the push is the old slot 0 — unless the stack was empty (the shift loop does not run: slot 1 keeps its stale
             // value) or full (the push is dropped: both slots stay)
-            if (ND < 0.0f) { const bool full = p.stackSize >= 10; n1 = (full || p.stackSize == 0) ? s1 : s0; n2 = full ? s0 : m.Ni; addToIndiceStack<STK>(p, (uint32_t)m.niCode); }
+            if (ND < 0.0f) { const bool full = p.stackSize >= 10; n1 = (full || p.stackSize == 0) ? s1 : s0; n2 = full ? s0 : m.Ni; addToIndiceStack<STK>(p, stackElemOf<STK>(m)); }
             else { n1 = s0; n2 = s1; removeFirstOfIndiceStack<STK>(p); }                       // :838-840
         }
         w = chooseLobe<FAST>(m, n1, n2, N, D, p.rng);         // :843 up to the lobe decision

@@ -98,6 +98,7 @@ __device__ __forceinline__ bool queueIn(const Control* ctl, int iter) { return c
 
 struct State {              // SoA path pool, float4 groups (see header comment)
     float4 *G0, *G1, *G2, *G3, *G4, *G5, *S0, *H;
+    unsigned s0Plane;       // STK == 32 (the index stack as ten floats): S0 holds three planes of this many slots — stack slots 0-3, 4-7, 8-9
     uint2* J;               // (frame slot of the stream, accumulator slot) of the slot's job: written when the job starts, read when it ends
     float4* HX;             // (u, v, id) of the closest triangle behind an ellipsoid hit; only for scenes whose ellipsoids carry texture-mapped materials
 };
@@ -165,6 +166,11 @@ __global__ void k_frame_setup(DevScene sc, const FrameIn* in, FrameConst* fc, El
 //   G0 = O.xyz, D.x    G1 = D.yz, rngState, flags    G2 = throughput.rgb, index-stack codes (3-bit scenes)    G4 = sum over samples.rgb, pixel x | y << 16
 //   G3 = incLight.rgb of the running sample, touched only while FL_INCNZ (pt_device.hpp)      J = (frame slot, accumulator slot), job start / job end only
 //   G5 = RAY_ENTER_LOCATION, DISTANCE_TRAVELED and S0 = index-stack codes of an 8-bit scene: scenes with transmissive materials only
+__device__ __forceinline__ void storeStack32(const State& st, unsigned i, const Path& p) {
+    stS(st.S0 + i, make_float4(__uint_as_float(p.sk[0]), __uint_as_float(p.sk[1]), __uint_as_float(p.sk[2]), __uint_as_float(p.sk[3])));
+    stS(st.S0 + st.s0Plane + i, make_float4(__uint_as_float(p.sk[4]), __uint_as_float(p.sk[5]), __uint_as_float(p.sk[6]), __uint_as_float(p.sk[7])));
+    stS(st.S0 + 2 * (size_t)st.s0Plane + i, make_float4(__uint_as_float(p.sk[8]), __uint_as_float(p.sk[9]), 0.0f, 0.0f));
+}
 template <int STK>
 __device__ __forceinline__ void storePath(const State& st, unsigned i, const Path& p) {
     stS(st.G0 + i, make_float4(p.O.x, p.O.y, p.O.z, p.D.x));
@@ -175,6 +181,7 @@ __device__ __forceinline__ void storePath(const State& st, unsigned i, const Pat
     st.J[i] = make_uint2(p.fi, p.ls);
     if (STK) st.G5[i] = make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist);
     if (STK == 8) st.S0[i] = make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f);
+    if (STK == 32) storeStack32(st, i, p);
 }
 
 // A new pixel-frame job (one fragment-shader invocation): fresh "globals" (SURVEY.md Q-1), rngState = index + u_seed.
@@ -194,6 +201,8 @@ __device__ __forceinline__ void startJob(const Batch& b, const FrameConst& fc, u
     p.applyAbs = false; p.inObj = false;
     p.enter = v3(0.0f); p.dist = 0.0f;
     p.sc0 = 0u; p.sc1 = 0u; p.sc2 = 0u;                         // every slot of the index stack 0.0 (dictionary code 0)
+#pragma unroll
+    for (int k = 0; k < 10; k++) p.sk[k] = 0u;
     p.stackSize = 0;
     p.incNZ = false; p.inc = v3(0.0f);
     p.alive = true;
@@ -563,7 +572,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     const unsigned q = blockIdx.x * SHADE_BLOCK + threadIdx.x;
     const bool valid = q < n;
     const unsigned i = valid ? (queue ? queue[q] : q) : 0u;
-    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, g5 = g0;
+    float4 g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0, g3 = g0, g4 = g0, h = g0, s0 = g0, s1 = g0, s2 = g0, g5 = g0;
     // Path tracing decides BEFORE it shades whether the segment ends its sample (segmentEndsSample: the hit record, the throughput and the bounce count say so):
     // the sum over the job's samples (G4, 16 B) and the job words (J) are then fetched by the lanes whose sample / job ends only — a segment in four — and the job
     // pull runs while those loads and the shading records are on their way.  directDiffuse learns it from the material (a subsurface hit goes on as a probe): old order.
@@ -571,7 +580,8 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
     if (valid) {
         g1 = ldS(st.G1 + i); g0 = ldS(st.G0 + i); h = ldS(st.H + i); g2 = ldS(st.G2 + i);
         if (!EARLY) g4 = ldS(st.G4 + i);
-        if (STK == 8) s0 = ldS(st.S0 + i);
+        if (STK == 8 || STK == 32) s0 = ldS(st.S0 + i);
+        if (STK == 32) { s1 = ldS(st.S0 + st.s0Plane + i); s2 = ldS(st.S0 + 2 * (size_t)st.s0Plane + i); }
         if (DIRECT) g3 = ldS(st.G3 + i);
     }
     const bool live = valid && (__float_as_uint(g1.w) & FL_ALIVE);
@@ -615,6 +625,11 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         g3in = make_float4(p.inc.x, p.inc.y, p.inc.z, 0.0f);
         if (STK == 8) { p.sc0 = __float_as_uint(s0.x); p.sc1 = __float_as_uint(s0.y); p.sc2 = __float_as_uint(s0.z); }
         else { p.sc0 = __float_as_uint(g2.w); p.sc1 = 0u; p.sc2 = 0u; }
+        if (STK == 32) {
+            p.sk[0] = __float_as_uint(s0.x); p.sk[1] = __float_as_uint(s0.y); p.sk[2] = __float_as_uint(s0.z); p.sk[3] = __float_as_uint(s0.w);
+            p.sk[4] = __float_as_uint(s1.x); p.sk[5] = __float_as_uint(s1.y); p.sk[6] = __float_as_uint(s1.z); p.sk[7] = __float_as_uint(s1.w);
+            p.sk[8] = __float_as_uint(s2.x); p.sk[9] = __float_as_uint(s2.y);
+        }
         isProbe = DIRECT && p.probe;
         if (DIRECT) {
             sampleDone = directSegment<TEX>(sc, p, h.x, h.y, h.z, __float_as_int(h.w), st.HX, i);      // RAYTRACING == 0 (frag.glsl:911-912)
@@ -708,6 +723,7 @@ __global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, con
         if (sampleDone) stS(st.G4 + i, make_float4(p.sum.x, p.sum.y, p.sum.z, __uint_as_float(p.pix)));
         if (newJob) st.J[i] = make_uint2(p.fi, p.ls);
         if (STK == 8) stS(st.S0 + i, make_float4(__uint_as_float(p.sc0), __uint_as_float(p.sc1), __uint_as_float(p.sc2), 0.0f));
+        if (STK == 32) storeStack32(st, i, p);
         if (TRANS) { if (p.g5dirty || newJob) stS(st.G5 + i, make_float4(p.enter.x, p.enter.y, p.enter.z, p.dist)); }
     }
     if (STATS) {                                  // statistics (count mode only): one atomic per wave
@@ -870,7 +886,7 @@ struct pt_ctx {
     // device scene
     float4 *dNodes = nullptr, *dTris = nullptr, *dShade = nullptr; ObjRoot* dRoots = nullptr; EllipRec* dEllip = nullptr; MatRec* dMats = nullptr;
     uchar4* dSky = nullptr; float* dNiTable = nullptr;
-    int niBits = 0;                 // index-stack encoding of the path state: 0 no transmissive material (the stack is unobservable), 3 or 8 bits per slot
+    int niBits = 0;                 // index-stack encoding of the path state: 0 no transmissive material (the stack is unobservable), 3 or 8 bits per slot, 32: the floats themselves
     unsigned char* dDisplay = nullptr;      // scratch of pt_read_display (W*H*3 bytes, allocated on first use)
     DevScene sc{};
     // shard
@@ -913,7 +929,7 @@ struct pt_ctx {
     bool noneMinSet = false;        // pt_set_option 3 was used
     int streamsOnDevice = 1;        // streams of the same multi-stream context on this context's GPU (pt_create_multi)
     bool extendCacheSet = false;    // pt_set_option 6 was used: the tile size is the caller's
-    bool forceNiBits8 = false;      // pt_set_option 18 (tests): 8-bit index-stack codes even when the scene's dictionary fits 3 bits
+    int forceNiBits8 = 0;           // pt_set_option 18 (tests): 1 = 8-bit index-stack codes even when the scene's dictionary fits 3 bits, 2 = the float stack
     bool fastContract = false, streamFast = false;      // the relaxed numeric contract (pt_set_option 16) as set / as the running stream was started with
     int asmLoop = -1;               // hand-written kernel's main loop: -1 automatic, 0 phase-voting, 1 fused trip (pt_set_option 14)
     int stackMode = 2, stackModeForce = -1;      // 0: short entries, 1: Packed18, 2: int (see k_extend_persist); Force: pt_set_option 11
@@ -1002,8 +1018,9 @@ int buildScene(pt_ctx* c) {
         if (code < 0) { code = (int)niDict.size(); niDict.push_back(mats[m].Ni); }
         mats[m].niCode = code;
     }
-    if (c->trans && niDict.size() > 256) return fail(PT_ERR_UNSUPPORTED, "more than 254 distinct refraction indices (Ni) among the materials of a scene with transmissive materials");
-    c->niBits = !c->trans ? 0 : ((niDict.size() <= 8 && !c->forceNiBits8) ? 3 : 8);
+    // (more values than the 8-bit dictionary holds, 0.0 and 1.0029 included: the path state carries the ten floats of the shader's stack themselves, frag.glsl:136-158)
+    c->niBits = !c->trans ? 0 : (niDict.size() > 256 || c->forceNiBits8 == 2) ? 32 : ((niDict.size() <= 8 && !c->forceNiBits8) ? 3 : 8);
+    if (niDict.size() > 256) { niDict.resize(256); for (auto& m : mats) if (m.niCode > 255) m.niCode = 0; }      // (the codes are not read in that form)
     niDict.resize(std::max<size_t>(niDict.size(), 8), 0.0f);
     // objects / BVH
     int numObj = c->objidx[0];
@@ -1269,13 +1286,13 @@ int ensurePool(pt_ctx* c, int capacity) {               // capacity >= poolActiv
     for (unsigned** q : {&c->dQueue[0], &c->dQueue[1]}) if (*q) { HIP_TRY(hipFree(*q)); *q = nullptr; }
     size_t n = (size_t)capacity;
     for (int k = 0; k < 9; k++) {
-        if ((k == 6 && c->niBits == 0) || (k == 7 && c->niBits != 8) || (k == 8 && !c->ellipMaps)) continue;      // G5: transmissive scenes; S0: 8-bit index-stack codes; HX: mapped ellipsoids
-        HIP_TRY(hipMalloc((void**)groups[k], n * 16));
+        if ((k == 6 && c->niBits == 0) || (k == 7 && c->niBits < 8) || (k == 8 && !c->ellipMaps)) continue;      // G5: transmissive scenes; S0: 8-bit index-stack codes, or three planes of floats; HX: mapped ellipsoids
+        HIP_TRY(hipMalloc((void**)groups[k], n * 16 * ((k == 7 && c->niBits == 32) ? 3 : 1)));
     }
     HIP_TRY(hipMalloc((void**)&c->st.J, n * 8));
     HIP_TRY(hipMalloc((void**)&c->dQueue[0], n * 4));
     HIP_TRY(hipMalloc((void**)&c->dQueue[1], n * 4));
-    c->allocSlots = capacity; c->allocNiBits = c->niBits; c->allocHX = c->ellipMaps;
+    c->allocSlots = capacity; c->allocNiBits = c->niBits; c->allocHX = c->ellipMaps; c->st.s0Plane = (unsigned)capacity;
     return 0;
 }
 
@@ -1556,6 +1573,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             if (direct) SHADE_X(0, true);
             else if (c->niBits == 3) SHADE_X(3, false);
             else if (c->niBits == 8) SHADE_X(8, false);
+            else if (c->niBits == 32) SHADE_X(32, false);
             else SHADE_X(0, false);
             c->iter = (c->iter + 1) & 0x3fffffff;
             iters++;
@@ -1707,6 +1725,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     //  scene with transmissive materials has the groups allocated, which k_revive<niBits> initialises)
     if (c->niBits == 3) { if (fastRevive) REVIVE(3, true); else REVIVE(3, false); }
     else if (c->niBits == 8) { if (fastRevive) REVIVE(8, true); else REVIVE(8, false); }
+    else if (c->niBits == 32) { if (fastRevive) REVIVE(32, true); else REVIVE(32, false); }
     else { if (fastRevive) REVIVE(0, true); else REVIVE(0, false); }
 #undef REVIVE
     c->streamFrames += (unsigned)nFrames; c->streamJobs += (unsigned)nJobs64;
@@ -2202,7 +2221,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 4: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "extend mode must be 0, 1 or 2"); c->extendMode = (int)value; return PT_OK;
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 19: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "node records of the hand-written kernel: -1 automatic, 0 80-B sign-ordered, 1 64-B"); c->asmNodeLayout = (int)value; c->sceneDirty = true; return PT_OK;
-        case 18: c->forceNiBits8 = value != 0; c->sceneDirty = true; return PT_OK;
+        case 18: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "index-stack encoding: 0 automatic, 1 at least 8-bit codes, 2 the floats themselves"); c->forceNiBits8 = (int)value; c->sceneDirty = true; return PT_OK;
         case 20: c->asmNoRootCull = value == 0; c->sceneDirty = true; return PT_OK;
         case 17: if (value != 0 && value != 256 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;

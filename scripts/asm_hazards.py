@@ -196,12 +196,7 @@ class Program:
 
 # Findings the scan cannot clear by itself because it does not track exec masks: (rule, producer regex, consumer regex, why it is not a hazard).
 # A waiver is applied only by scan(..., waive=True); what it suppressed is returned beside the findings, and the test pins the exact set.
-WAIVERS = [
-    ("V", r"ds_read_[iu]16 v1, v16", r"v_add_u32_e32 v1, -1, v1",
-     "fused trip: the pop of the node step reads the stack entry into vCur for lanes of s[64:65] (cur >= 0, no child to enter), the triangle step "
-     "that follows advances vCur of lanes of s[66:67] (cur < 0): the two masks are disjoint by construction, LDS returns and VALU writes are per "
-     "lane, and POP_FINISH waits lgkmcnt(0) before any lane of either mask reads vCur"),
-]
+WAIVERS = []      # (round 5: the one former entry — the node step's pop into vCur against the triangle step's advance of vCur — is gone from the kernel: pops land in vPop)
 
 
 def scan(path, waive=False):

@@ -30,7 +30,7 @@ t0 = time.time()
 for seed in range(first, first + count):
     wl = T._random_workload(pt, seed, ellipsoid_maps=seed % 3 == 0)
     opts = dict(extend_tpb=[256, 64, 256, 1024, 256][seed % 5], stack_mode=[-1, -1, 1, 2][seed % 4], refill_min=[1, 8, 24, 48][(seed // 5) % 4],
-                index_stack_8bit=seed % 2, asm_node_layout=[-1, 0, 1][seed % 3], asm_tpb=[0, 256, 1024][(seed // 3) % 3], asm_loop=[-1, 0, 1][(seed // 7) % 3])
+                index_stack_8bit=(seed // 2) % 3, asm_node_layout=[-1, 0, 1][seed % 3], asm_tpb=[0, 256, 1024][(seed // 3) % 3], asm_loop=[-1, 0, 1][(seed // 7) % 3], asm_root_cull=(seed // 5) % 2)
     try:
         got, ref, cnt, ocnt = T.render_both(pt, oracle, renderer, wl, 3, **opts)
         T.assert_same(got, ref, cnt, ocnt)

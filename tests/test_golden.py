@@ -45,7 +45,8 @@ def test_oracle_and_packers_reproduce_golden(pt, oracle, path):
         assert np.array_equal(wl.buffers[k], v, equal_nan=True), f"binding {k}"
     assert sorted(wl.textures) == sorted(tex) and all(np.array_equal(wl.textures[i], tex[i]) for i in tex)
     frame, cnt = oracle.render_frames(oracle.Scene(bufs, z["sky"], tex), W, H, 1, len(z["seeds"]), z["seeds"], nthreads=3)
-    assert _same(frame, z["frame"]) and np.array_equal(cnt, z["counters"])
+    n = len(z["counters"])                # the fixtures hold SURVEY.md 8(d)'s counters; the traversal-shape counters appended in round 5 (oracle.COUNTERS[8:]) are not part of them
+    assert _same(frame, z["frame"]) and np.array_equal(cnt[:n], z["counters"])
 
 
 @pytest.mark.gpu

@@ -504,8 +504,8 @@ def test_errors_surface(pt, renderer_mod):
     with pytest.raises(renderer_mod.PtError) as e:
         r.render(1, 1)
     assert e.value.code == -4
-    # the limits of the slot encoding surface as errors, not as wrong images: SAMPLE_RES beyond the 11-bit counter, and more distinct refraction
-    # indices than the index-stack dictionary holds in a scene with a transmissive material (the same scene without one renders: the stack is unobservable)
+    # the limit of the slot encoding surfaces as an error, not as a wrong image: SAMPLE_RES beyond the 11-bit counter.  (More distinct refraction indices than
+    # the index-stack dictionary holds used to be one too; such a scene now carries the ten floats of the stack: test_more_refraction_indices_than_the_dictionary_holds)
     r.set_buffer(3, wl.buffers[3])
     p = wl.buffers[4].copy(); p[4] = 2048.0
     r.set_buffer(4, p)
@@ -523,9 +523,7 @@ def test_errors_surface(pt, renderer_mod):
     r.render(1, 1)                                            # no transmissive material: any number of Ni values
     mtl[me * 7 + 12] = 0.5                                    # Tr > 0 on one of them
     r.set_buffer(14, mtl)
-    with pytest.raises(renderer_mod.PtError) as e:
-        r.render(2, 2)
-    assert e.value.code == -5 and "refraction indices" in str(e.value)
+    r.render(2, 2)                                            # ... and with one: the float-stack state (parity: the test named above)
     r.close()
 
 
@@ -1173,10 +1171,36 @@ def test_nested_transmissive_shells(pt, oracle, renderer_mod, shells):
     assert_same(got, ref)
 
 
+@pytest.mark.parametrize("shells", [5, 11])
+def test_more_refraction_indices_than_the_dictionary_holds(pt, oracle, renderer_mod, shells):
+    """The shader's refraction-index stack holds any float (frag.glsl:136-158, :834).  The path state normally carries it as dictionary codes (3 or 8 bits per slot);
+    a scene with more than 254 distinct Ni among its materials — here the nested transmissive shells plus 300 materials that only widen the dictionary — switches to
+    the state variant that carries the ten floats themselves (k_shade<32>), and the same variant forced onto the plain scene must give the same bits."""
+    wl = _nested_shells_workload(pt, shells=shells)
+    got32, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=2)
+    assert_same(got32, ref, cnt, ocnt)
+    b = dict(wl.buffers)
+    mtl = np.asarray(b[14], np.float32); me = int(mtl[0])
+    extra = np.tile(mtl[1:1 + me], 300).reshape(300, me).copy()
+    extra[:, 16] = 2.0 + 0.001 * np.arange(300, dtype=np.float32)       # Ni (dispatch.java:272-324: slot 16 of the record)
+    b[14] = np.concatenate([mtl, extra.reshape(-1)]).astype(np.float32)
+    wide = pt.scenes.Workload("shells+300", wl.W, wl.H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
+    got, ref2, cnt, ocnt = render_both(pt, oracle, renderer_mod, wide, 3)
+    assert_same(got, ref2, cnt, ocnt)
+    assert np.array_equal(ref, ref2, equal_nan=True)                  # (the extra materials are never hit)
+    r = renderer_mod.Renderer(wl.W, wl.H, devices=[0, 0])              # overlapped batches on the two-stream group, the pool growing under them
+    seeds = seeds_for(pt, 1, 4)
+    r.load_workload(wide); r.reset_frame()
+    r.render_batch_async(1, seeds[:1]); r.render_batch_async(2, seeds[1:])
+    got = r.read_frame(); r.close()
+    ref4, _ = oracle.render_frames(oracle.Scene.from_workload(wide), wl.W, wl.H, 1, 4, seeds, nthreads=8)
+    assert_same(got, ref4)
+
+
 @pytest.mark.parametrize("seed", list(range(1, 19)))
 def test_random_scenes(pt, oracle, renderer_mod, seed):
     wl = _random_workload(pt, seed, ellipsoid_maps=seed > 12)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=seed % 2)      # both encodings of the index stack in the path state
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=seed % 3)      # the three encodings of the index stack in the path state (3-bit / 8-bit codes, floats)
     assert_same(got, ref, cnt, ocnt)
     direct = wl.with_params(RAYTRACING=0)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, direct, 2, extend_mode=seed % 2)
