@@ -921,7 +921,7 @@ struct pt_ctx {
     uint64_t asmLaunches = 0;
     bool asmEligible = false;       // this scene can run on the hand-written kernel (buildScene)
     std::string asmWhyNot;          // ... or why not (pt_debug: reported by option 12)
-    hipModule_t asmModule[8] = {}; hipFunction_t asmFn[8] = {}; std::string asmLoadError[8];      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract); [4..7] the same four with 1024-thread blocks
+    hipModule_t asmModule[12] = {}; hipFunction_t asmFn[12] = {}; std::string asmLoadError[12];      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract); [4..7] the same four with 1024-thread blocks, [8..11] with 512-thread blocks
     int asmTpb = 0;                 // threads per block of the hand-written kernel: 0 automatic (launchExtendAsm), 256, 1024
     bool debugExactExtend = false;  // pt_debug_intersect always probes the exact kernels
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
@@ -1123,11 +1123,10 @@ int buildScene(pt_ctx* c) {
     // min / max.  Trees that do not fit the caches pay for those bytes on every node visit (C4: 552 B per segment, the chip at 0.61 of its HBM peak):
     // they get 64-B records — references, pad, (Lmin, Rmin | Lmax, Rmax) per axis — and the kernel's min/max step (pt_set_option 19 overrides).
     const size_t nInner = order.size();
-    size_t largestTree = 0;                                       // inner nodes of the largest BVH
-    { std::vector<size_t> per(std::max(numObj, 1), 0); for (int n : order) per[objOf[n]]++; for (size_t v : per) largestTree = std::max(largestTree, v); }
-    // (what decides is the tree a ray walks deep into: C4's single 100 k-node tree gains 5 % from the small records, C6's 64 trees of 1.5 k nodes —
-    //  as many bytes in all — lose 2 %: profiles/r04_d_node_record_layout.txt)
-    const int asmStride = c->asmNodeLayout == 0 ? 80 : c->asmNodeLayout == 1 ? 64 : (largestTree * 80 > (size_t)ASM_NODES_80B_LIMIT ? 64 : 80);
+    // (what decides is whether the records the rays walk through fit an XCD's L2 beside the state stream: C4's single 100 k-node tree gains 5 % from the small
+    //  records — and so do C6's 64 trees of 1.5 k nodes, 7.8 MB in all, +6.2 %, since the per-ray cull of the object loop took the 64 root tests per ray out of its
+    //  vector instructions; round 4, before the cull, measured -2 % there and chose by the largest tree: profiles/r04_d_node_record_layout.txt, r05_f_*)
+    const int asmStride = c->asmNodeLayout == 0 ? 80 : c->asmNodeLayout == 1 ? 64 : (nInner * 80 > (size_t)ASM_NODES_80B_LIMIT ? 64 : 80);
     const int W_ = asmStride / 4;
     std::vector<float> nodes80(std::max<size_t>(nInner, 1) * W_ + 40, 0.0f);      // (+ 160 B: developer builds of the kernel read behind a record, -DFETCH_EXTRA)
     bool boxesOrdered = true, anyEmpty = false;
@@ -1350,8 +1349,9 @@ static_assert(sizeof(EllipRec) == 128 && offsetof(EllipRec, rotated) == 32 && of
 int loadAsmKernel(pt_ctx* c, int k) {
     if (c->asmFn[k]) return 0;
     if (!c->asmLoadError[k].empty()) return fail(PT_ERR_HIP, c->asmLoadError[k]);
-    const void* images[8] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f,
-                             pt_extend_hsaco_s16w, pt_extend_hsaco_p18w, pt_extend_hsaco_s16fw, pt_extend_hsaco_p18fw};
+    const void* images[12] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f,
+                              pt_extend_hsaco_s16w, pt_extend_hsaco_p18w, pt_extend_hsaco_s16fw, pt_extend_hsaco_p18fw,
+                              pt_extend_hsaco_s16h, pt_extend_hsaco_p18h, pt_extend_hsaco_s16fh, pt_extend_hsaco_p18fh};
     hipModule_t m = nullptr; hipFunction_t f = nullptr;
     hipError_t e = hipModuleLoadData(&m, images[k]);
     if (e == hipSuccess) e = hipModuleGetFunction(&f, m, "pt_extend_asm");
@@ -1406,7 +1406,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     int perCU = std::max(1, std::min((int)(ldsPerCU / lds), maxBlocks));
     int grid = c->numCUs * perCU;
     grid = std::max(1, std::min(grid, ((int)pr.launched + TPB - 1) / TPB));
-    const int variant = (c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0) + (TPB == 1024 ? 4 : 0);
+    const int variant = (c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0) + (TPB == 1024 ? 4 : TPB == 512 ? 8 : 0);
     if (loadAsmKernel(c, variant)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
@@ -2223,7 +2223,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 19: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "node records of the hand-written kernel: -1 automatic, 0 80-B sign-ordered, 1 64-B"); c->asmNodeLayout = (int)value; c->sceneDirty = true; return PT_OK;
         case 18: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "index-stack encoding: 0 automatic, 1 at least 8-bit codes, 2 the floats themselves"); c->forceNiBits8 = (int)value; c->sceneDirty = true; return PT_OK;
         case 20: c->asmNoRootCull = value == 0; c->sceneDirty = true; return PT_OK;
-        case 17: if (value != 0 && value != 256 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256 or 1024"); c->asmTpb = (int)value; return PT_OK;
+        case 17: if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256, 512 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)
         case 12: {                                                // query (debug): 0 = the current scene runs on the hand-written intersect kernel, else PT_ERR_UNSUPPORTED + why not

@@ -245,12 +245,14 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
                                               ("C6", 64, 36, {}, {}), ("C6", 64, 36, {}, {"asm_loop": 0}), ("C6", 64, 36, {}, {"asm_tpb": 1024, "none_min": 1}),
                                               # node records of the other layout than the automatic choice (80-B sign-ordered for trees that fit the caches, else 64-B + the min/max step)
                                               ("C3", 96, 54, {}, {"asm_node_layout": 1}), ("C3", 96, 54, {}, {"asm_node_layout": 1, "asm_loop": 0, "asm_tpb": 1024}), ("C4", 64, 36, {}, {"asm_node_layout": 0}),
-                                              ("C6", 64, 36, {}, {"asm_node_layout": 1}), ("C2", 96, 54, {}, {"asm_node_layout": 1}),
+                                              ("C6", 64, 36, {}, {"asm_node_layout": 1}), ("C6", 64, 36, {}, {"asm_node_layout": 0, "asm_loop": 0}), ("C2", 96, 54, {}, {"asm_node_layout": 1}),
                                               ("C6", 64, 36, {"groups": 11, "nu": 8, "nv": 8}, {"refill_min": 64}), ("C6", 64, 36, {"groups": 9, "nu": 6, "nv": 6}, {"asm_loop": 0, "none_min": 32}),
                                               # the per-ray cull of the object loop (round 5): off; more BVHs than mask bits — groups of 2, 4 and 16 BVHs per bit
                                               ("C6", 64, 36, {}, {"asm_root_cull": 0}), ("C6", 64, 36, {"groups": 70, "nu": 6, "nv": 6}, {}),
                                               ("C6", 64, 36, {"groups": 130, "nu": 4, "nv": 4}, {"asm_loop": 0, "refill_min": 1}), ("C6", 64, 36, {"groups": 600, "nu": 4, "nv": 4}, {"asm_tpb": 1024}),
-                                              ("C6", 64, 36, {"groups": 65, "nu": 4, "nv": 4}, {"asm_node_layout": 1, "none_min": 1})])
+                                              ("C6", 64, 36, {"groups": 65, "nu": 4, "nv": 4}, {"asm_node_layout": 1, "none_min": 1}),
+                                              # 512-thread blocks
+                                              ("C3", 96, 54, {}, {"asm_tpb": 512}), ("C4", 64, 36, {}, {"asm_tpb": 512, "asm_loop": 0}), ("C6", 64, 36, {}, {"asm_tpb": 512, "refill_min": 8})])
 def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
     """pt_extend_gfx950.s against the compiled kernels on 64 K rays per scene, a sixteenth of them irregular (zero, denormal, infinite, NaN
     components: the rays that take its min/max step): every hit record bit for bit.  C4 and the last case run its 18-bit-stack form;
