@@ -28,7 +28,7 @@ first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
 t0 = time.time()
 for seed in range(first, first + count):
-    wl = T._random_workload(pt, seed, ellipsoid_maps=seed % 3 == 0)
+    wl = T._random_workload(pt, seed, ellipsoid_maps=seed % 3 == 0 and seed % 4 != 3, many_groups=seed % 4 == 3)
     opts = dict(extend_tpb=[256, 64, 256, 1024, 256][seed % 5], stack_mode=[-1, -1, 1, 2][seed % 4], refill_min=[1, 8, 24, 48][(seed // 5) % 4],
                 index_stack_8bit=(seed // 2) % 3, asm_node_layout=[-1, 0, 1][seed % 3], asm_tpb=[0, 256, 1024][(seed // 3) % 3], asm_loop=[-1, 0, 1][(seed // 7) % 3], asm_root_cull=(seed // 5) % 2)
     try:

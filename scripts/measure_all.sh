@@ -41,3 +41,6 @@ for f in sorted(glob.glob("$O/bench_*.json")):
             d=json.loads(l); r=d.get("roofline",{})
             print(f.split("/")[-1], d["value"], "Ms/s", d["ms_per_step"], "ms/step", "frac", r.get("frac"), "hbm", (r.get("hbm") or {}).get("frac"), "shade", (r.get("shade") or {}).get("frac"), "parity", d.get("parity"))
 PY
+# 5. the launches the hand-written kernel does not take, and a fuzz campaign over the switches
+timeout -k 10 400 python3 scripts/fallback_paths.py 2>&1 | grep -v amdgpu.ids | tee $O/fallback_paths.txt
+timeout -k 10 600 python3 scripts/fuzz_campaign.py 70001 400 2>&1 | tail -3 | tee $O/fuzz.txt

@@ -1073,7 +1073,7 @@ def test_n3_mapped_material_on_ellipsoids(pt, oracle, renderer_mod, raytracing, 
 
 
 # ---- randomized scenes: every material lobe, texture maps, ellipsoids (stretched, rotated), several objects, odd cameras — in combination
-def _random_workload(pt, seed, W=72, H=44, ellipsoid_maps=False):
+def _random_workload(pt, seed, W=72, H=44, ellipsoid_maps=False, many_groups=False):
     rs = np.random.RandomState(seed)
     sc = pt.hostlib.Scene()
     names = []
@@ -1106,10 +1106,11 @@ def _random_workload(pt, seed, W=72, H=44, ellipsoid_maps=False):
     o = pt.scenes.Obj()
     o.group("ground"); o.usemtl(names[0])
     o.quad_uv((-3, -0.5, -3), (3, -0.5, -3), (3, -0.5, 3), (-3, -0.5, 3), (0, 1, 0), (0.0, 0.0), (2.5, 2.5))
-    for g in range(rs.randint(1, 4)):
+    # many_groups: 9 .. 70 small `o` groups (more than 8 BVHs: root records in LDS and the per-ray cull of the object loop; beyond 64: two BVHs per mask bit)
+    for g in range(rs.randint(9, 71) if many_groups else rs.randint(1, 4)):
         o.group(f"soup{g}")
         centre = rs.uniform(-1.0, 1.0, 3) + np.array([0, 0.4, 0.5])
-        for _ in range(rs.randint(8, 120)):
+        for _ in range(rs.randint(8, 30) if many_groups else rs.randint(8, 120)):
             o.usemtl(names[rs.randint(0, n_mat)])
             c = centre + rs.normal(0, 0.45, 3)
             a, b2, c2 = (c + rs.normal(0, 0.18, 3) for _ in range(3))
@@ -1199,9 +1200,9 @@ def test_more_refraction_indices_than_the_dictionary_holds(pt, oracle, renderer_
     assert_same(got, ref4)
 
 
-@pytest.mark.parametrize("seed", list(range(1, 19)))
+@pytest.mark.parametrize("seed", list(range(1, 25)))
 def test_random_scenes(pt, oracle, renderer_mod, seed):
-    wl = _random_workload(pt, seed, ellipsoid_maps=seed > 12)
+    wl = _random_workload(pt, seed, ellipsoid_maps=12 < seed <= 18, many_groups=seed > 18)
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=seed % 3)      # the three encodings of the index stack in the path state (3-bit / 8-bit codes, floats)
     assert_same(got, ref, cnt, ocnt)
     direct = wl.with_params(RAYTRACING=0)
