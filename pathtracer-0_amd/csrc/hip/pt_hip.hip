@@ -2381,7 +2381,7 @@ int pt_debug_intersect(pt_ctx* c, const float* o, const float* d, float* out, si
         std::memcpy(c->streamIn.params, fin.params, 48); c->streamIn.params[9] = 1.0f;      // no thickness probes in this pool
         PoolRun pr; pr.stream = c->stream; pr.st = st; pr.launched = (unsigned)np; pr.iter = 0;
         c->debugExactExtend = true;
-        launchExtendPersist(c, pr);
+        TIMED_LAUNCH_ON(c->stream, 0, launchExtendPersist(c, pr));       // (pt_set_timing: scripts/coherence_probe.py times the production kernel on ray sets of its own)
         c->debugExactExtend = false;
         std::memset(&c->streamIn, 0xff, sizeof(FrameIn));
     }
