@@ -1264,7 +1264,6 @@ int buildScene(pt_ctx* c) {
     for (int o = 0; o < numObj; o++) if (roots[o].ref == REF_EMPTY) anyEmpty = true;
     c->asmWhyNot.clear();
     if (numObj < 1 || numObj > 1024) c->asmWhyNot = "no BVH or more than 1024";
-    else if (ellipMaps) c->asmWhyNot = "ellipsoids with texture-mapped materials";
     else if (anyEmpty) c->asmWhyNot = "a leaf without triangles";
     else if (!boxesOrdered && asmStride == 80) c->asmWhyNot = "a node box with min > max or a NaN";      // (the 64-B records' min/max step is rayBox as written)
     else if (c->stackMode == 2) c->asmWhyNot = "tree too large for 18-bit stack entries";
@@ -1336,8 +1335,9 @@ struct EpAsmArgs {
     void* dbg;                      // developer builds of the assembly (-DPT_ASM_DEBUG): 32 B per wave
     const void* ellip; int numEllip, nodeStride;      // EllipRec array (rotation matrices by k_frame_setup); bytes per node record (80 or 64)
     int groupShift, pad0;           // more than 8 BVHs: log2 of the objects per group box (the 64 group boxes follow the root records)
+    void* HX;                       // State::HX of scenes whose ellipsoids carry texture-mapped materials, else null
 };
-static_assert(sizeof(EpAsmArgs) == 144 && offsetof(EpAsmArgs, ellip) == 120 && offsetof(EpAsmArgs, groupShift) == 136, "EpAsmArgs layout is part of the assembly");
+static_assert(sizeof(EpAsmArgs) == 152 && offsetof(EpAsmArgs, HX) == 144 && offsetof(EpAsmArgs, ellip) == 120 && offsetof(EpAsmArgs, groupShift) == 136, "EpAsmArgs layout is part of the assembly");
 static_assert(sizeof(EllipRec) == 128 && offsetof(EllipRec, rotated) == 32 && offsetof(EllipRec, R) == 48, "EllipRec layout is part of the assembly");
 #ifndef PT_EXTEND_INC
 #define PT_EXTEND_INC "pt_extend_hsaco.inc"
@@ -1366,7 +1366,7 @@ int loadAsmKernel(pt_ctx* c, int k) {
 
 // true: launched.  false: this launch is not one the hand-written kernel takes (the caller uses the compiled kernel)
 bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
-    if (!c->asmEligible || c->countStats || c->streamIn.params[9] != 1.0f || c->ellipMaps || c->extendTpb != 256) return false;
+    if (!c->asmEligible || c->countStats || c->streamIn.params[9] != 1.0f || c->extendTpb != 256) return false;
     const DevScene& sc = c->sc;
     // Block size.  What bounds this kernel is its CU's instruction issue and vector-memory pipe together (profiles/r03_h_*): node steps served from
     // the LDS tile cost neither a tag lookup nor a round trip, and the tile is per BLOCK — the same bytes eight times over with 256-thread blocks.
@@ -1410,7 +1410,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     if (loadAsmKernel(c, variant)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
-    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride; a.groupShift = c->asmGroupShift;
+    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride; a.groupShift = c->asmGroupShift; a.HX = c->ellipMaps ? (void*)pr.st.HX : nullptr;
     a.numObj = sc.numObj; a.iter = pr.iter; a.nSlots = (int)pr.launched; a.refillMin = c->refillMin; a.keepEighths = c->innerKeepEighths; a.noneMin = c->noneMin;
     // main loop: the fused trip with fetch-at-decision, unless the whole scene sits in the LDS tile — then no fetch is worth hiding and the
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)

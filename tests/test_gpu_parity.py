@@ -16,7 +16,7 @@ def seeds_for(pt, first, n):
     return [pt.scenes.frame_seed(f) for f in range(first, first + n)]
 
 
-def render_both(pt, oracle, renderer_mod, wl, n_frames, first=1, count_stats=True, **opts):
+def render_both(pt, oracle, renderer_mod, wl, n_frames, first=1, count_stats=True, expect_asm=False, **opts):
     W, H = wl.W, wl.H
     seeds = seeds_for(pt, first, n_frames)
     r = renderer_mod.Renderer(W, H)
@@ -38,6 +38,8 @@ def render_both(pt, oracle, renderer_mod, wl, n_frames, first=1, count_stats=Tru
         shipped = r.read_frame()
         same = (shipped == got) | (np.isnan(shipped) & np.isnan(got))
         assert same.all(), f"shipped kernels differ from the counting variants in {int((~same).sum())} floats"
+        if expect_asm:
+            r.set_option("query_asm_launches_above", 0)          # raises unless the hand-written intersect kernel rendered the second pass
     r.close()
     sc = oracle.Scene.from_workload(wl)
     ref, ocnt = oracle.render_frames(sc, W, H, first, n_frames, seeds, nthreads=8)
@@ -1053,7 +1055,7 @@ def test_n3_missing_texture_is_an_error(pt, renderer_mod):
     r.close()
 
 
-@pytest.mark.parametrize("raytracing,mode", [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize("raytracing,mode", [(1, 2), (1, 1), (1, 0), (0, 1)])
 def test_n3_mapped_material_on_ellipsoids(pt, oracle, renderer_mod, raytracing, mode):
     """a texture-mapped material on an ellipsoid is sampled at the uv of the closest TRIANGLE the BVH loop found before it (hitUV is
     written at frag.glsl:574 only, not at :619-630), (0,0) when no triangle lies on the ray: C1's spheres over its ground quad"""
@@ -1066,7 +1068,8 @@ def test_n3_mapped_material_on_ellipsoids(pt, oracle, renderer_mod, raytracing, 
     tex = {1: rs.randint(0, 256, size=(5, 7, 4)).astype(np.uint8), 2: rs.randint(0, 256, size=(3, 2, 4)).astype(np.uint8)}
     wl = pt.scenes.Workload(wl1.name + "_mapped", wl1.W, wl1.H, b, wl1.sky, wl1.sample_res, wl1.max_bounces, dict(wl1.info), tex)
     wl = wl.with_params(RAYTRACING=raytracing)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, extend_mode=mode)
+    # (round 5: path tracing such a scene runs on the hand-written intersect kernel too — it leaves the triangle's (u, v, id) in the side record State::HX)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, extend_mode=mode, expect_asm=(mode == 2 and raytracing == 1))
     assert_same(got, ref, cnt, ocnt)
     plain, _, _, _ = render_both(pt, oracle, renderer_mod, wl1.with_params(RAYTRACING=raytracing), 3, extend_mode=mode)
     assert not np.array_equal(got, plain)         # the maps do change the picture
