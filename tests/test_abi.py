@@ -183,3 +183,56 @@ def test_c_client_names_every_boundary_symbol():
     src = open(os.path.join(ROOT, "tests", "c", "abi_client.c")).read()
     for n in declared("pt_api.h"):
         assert f"SYM(hip, {n})" in src, n
+
+
+def _build_jni_harness(tmp_path):
+    """pt_jni.c + tests/c/jni_harness.c (a JNIEnv made of plain C functions) -> an executable linked against libpt_hip.so"""
+    import subprocess
+    exe = str(tmp_path / "jni_harness")
+    lib = os.path.join(ROOT, "pathtracer-0_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I" + os.path.join(ROOT, "tests", "c", "jni_standin"), "-I" + os.path.join(ROOT, "include"),
+           "-o", exe, os.path.join(lib, "java", "pt_jni.c"), os.path.join(ROOT, "tests", "c", "jni_harness.c"), "-L" + lib, "-lpt_hip", "-Wl,-rpath," + lib]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    return exe
+
+
+def test_jni_shim_links_into_the_jvm_free_harness(pt, tmp_path):
+    """the shim, compiled for real (not -fsyntax-only) against the stand-in header, links with the harness and libpt_hip.so: every native it defines resolves"""
+    from pathtracer_0_amd import build
+    build.build_hip()
+    _build_jni_harness(tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_streams", [0, 1])
+def test_jni_shim_runs_without_a_jvm(pt, renderer_mod, tmp_path, two_streams):
+    """N1 one step further than a type check: pt_jni.c EXECUTES — a JNIEnv of plain C functions (tests/c/jni_harness.c: a direct buffer is (address, capacity),
+    an int[] is (length, data), a pending exception is (class, message)) drives the Java_Main_PtNative_* natives in the order the reference's Main would:
+    uploads from direct buffers, one draw, a batch, draws left in flight, glFinish, glReadPixels, the screenshot, counters, the image ring, the error paths
+    (heap buffer -> IllegalArgumentException, library error -> RuntimeException with pt_last_error()).  FRAME and the display bytes must equal what the
+    ctypes face renders.  It still pins nothing about a real JVM (no JDK here): the stand-in header is the builder's reading of the JNI specification."""
+    import subprocess
+    import numpy as np
+    W, H = 96, 54
+    wl = pt.scenes.build("C3", W, H)
+    d = tmp_path / "in"; d.mkdir()
+    for b in (0, 1, 2, 3, 4, 5, 7, 10, 11, 12, 13, 14):
+        np.ascontiguousarray(wl.buffers[b]).tofile(str(d / f"binding_{b}.bin"))
+    sky = np.ascontiguousarray(wl.sky, dtype=np.uint8)
+    sky.tofile(str(d / "sky.bin"))
+    exe = _build_jni_harness(tmp_path)
+    out = subprocess.run([exe, str(d), str(W), str(H), str(sky.shape[1]), str(sky.shape[0]), str(two_streams)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "JNI_HARNESS_OK" in out.stdout, out.stdout + out.stderr
+    assert "setBuffer(heap buffer) -> java/lang/IllegalArgumentException" in out.stdout and "render without a scene -> java/lang/RuntimeException" in out.stdout
+    seeds = [9153, 7072, 4991, 2910, 829, 8748]
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame(); r.reset_counters()
+    r.render_batch(1, seeds)
+    ref = r.read_frame().copy(); disp = r.read_display(6, java_bytes=True); cnt = r.counters(); r.close()
+    got = np.fromfile(str(d / "frame.bin"), dtype=np.float32).reshape(H, W, 4)
+    assert np.array_equal(got, ref, equal_nan=True) and np.all(got[..., 3] == 6)
+    assert np.array_equal(np.fromfile(str(d / "display.bin"), dtype=np.uint8).reshape(disp.shape), disp)
+    line = [l for l in out.stdout.splitlines() if l.startswith("counters:")][0].split()[1:]
+    assert int(line[4]) == cnt["samples"] and int(line[0]) == cnt["segments"]            # PT_CNT_SEGMENTS, PT_CNT_SAMPLES through getCounters' long[]
+    assert os.path.getsize(str(d / "shot.png")) > 100
