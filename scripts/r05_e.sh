@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: (1) always-enter variant of the lazy next-BVH step on C6; (2) cycles per trip against waves per SIMD (what saturates?)
+# libraries: scripts/build_variant.py enter -DLAZY_ENTER=1; cull3; prof -DPT_ASM_DEBUG -DPT_ASM_PROF --hip -DPT_ASM_DEBUG
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r05e}; O=$R/gpurun_out/$T; mkdir -p $O; cd $R
 PT_HIP_LIB=$R/build/ab/enter.so timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -x -q -k "equals_compiled or root_cull or render_parity_handwritten" > $O/parity_enter.txt 2>&1; rc=$?

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: 512-thread blocks (3 per CU over a 32 KB tile) when two streams share the GPU; 64-B node records on C6 after the object-loop cull
+# library: scripts/build_variant.py cur
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-r05j}; O=$R/gpurun_out/$T; mkdir -p $O; cd $R
 timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -x -q -k "equals_compiled" > $O/parity.txt 2>&1; rc=$?; echo "parity rc=$rc $(tail -1 $O/parity.txt)"; [ $rc = 0 ] || { tail -30 $O/parity.txt; exit 1; }
