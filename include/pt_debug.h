@@ -14,12 +14,13 @@ extern "C" {
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8, 2 in the fused loop of the hand-written kernel; 1 = at once),
  * 4 = intersect kernel (0 simple, one block per 256 rays; 1 persistent blocks, compiled; 2 = default: the hand-written form of 1, csrc/hip/pt_extend_gfx950.s,
- *     for the launches it takes — at most 1024 BVHs, no empty leaves, ordered boxes, RAYTRACING == 1, statistics off — and 1 for the others),
+ *     for the launches it takes — at most 1024 BVHs, no empty leaves, ordered boxes, fewer than 2^23 - 1 inner nodes / triangle records, RAYTRACING == 1, statistics off — and 1 for the others),
  * 5 = persistent block size (64/128/256/512/1024, default 256), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on the blocks per CU of the persistent grid (default 0 = no cap: as many as are resident at once, 8 blocks of 256 threads = 8 waves per SIMD),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6),
  * 10 = inner-node records kept in breadth-first order (whole levels, the top of the trees); deeper ones are laid out depth-first,
- * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 32-bit; -1 = automatic.
+ * 11 = width of the traversal-stack entries at least: 0 16-bit, 1 16 bits in LDS + 2 bits in registers (trees up to 131071 nodes), 2 the widest (compiled kernel: 32-bit;
+ *      hand-written kernel: 16 bits + a byte in a second LDS array, trees up to 2^23 - 2 inner nodes / triangle records); -1 = automatic.
  * 14 = main loop of the hand-written intersect kernel: -1 automatic (default), 0 phase-voting like the compiled kernel, 1 fused trip (every lane on a node or
  *      a leaf advances each trip; a lane's record is requested the moment its entry is decided).
  * 17 = block size of the hand-written intersect kernel: 0 automatic (default: 1024 threads — 2 blocks per CU over a 32 KB tile of the trees' top — when the

@@ -921,7 +921,8 @@ struct pt_ctx {
     uint64_t asmLaunches = 0;
     bool asmEligible = false;       // this scene can run on the hand-written kernel (buildScene)
     std::string asmWhyNot;          // ... or why not (pt_debug: reported by option 12)
-    hipModule_t asmModule[12] = {}; hipFunction_t asmFn[12] = {}; std::string asmLoadError[12];      // [0] 16-bit stack entries, [1] Packed18; [2], [3] the same with v_rcp_f32 (relaxed contract); [4..7] the same four with 1024-thread blocks, [8..11] with 512-thread blocks
+    // per block size (256, 1024, 512 threads) six code objects: 16-bit stack entries, Packed18, the same two with v_rcp_f32 (relaxed contract), 24-bit entries exact / relaxed
+    hipModule_t asmModule[18] = {}; hipFunction_t asmFn[18] = {}; std::string asmLoadError[18];
     int asmTpb = 0;                 // threads per block of the hand-written kernel: 0 automatic (launchExtendAsm), 256, 1024
     bool debugExactExtend = false;  // pt_debug_intersect always probes the exact kernels
     int extendTpb = 256, extendCacheBytes = 8 * 1024, refillMin = 24, numCUs = 256;
@@ -1266,8 +1267,7 @@ int buildScene(pt_ctx* c) {
     if (numObj < 1 || numObj > 1024) c->asmWhyNot = "no BVH or more than 1024";
     else if (anyEmpty) c->asmWhyNot = "a leaf without triangles";
     else if (!boxesOrdered && asmStride == 80) c->asmWhyNot = "a node box with min > max or a NaN";      // (the 64-B records' min/max step is rayBox as written)
-    else if (c->stackMode == 2) c->asmWhyNot = "tree too large for 18-bit stack entries";
-    else if (triRecs.size() / 3 >= (1u << 24) || order.size() >= (1u << 24)) c->asmWhyNot = "more than 2^24 records";
+    else if (triRecs.size() / 3 >= (1u << 23) - 1 || order.size() >= (1u << 23) - 1) c->asmWhyNot = "more than 2^23 - 2 inner nodes or triangle records (24-bit stack entries)";
     c->asmEligible = c->asmWhyNot.empty();
     c->sceneDirty = false;
     return 0;
@@ -1334,7 +1334,7 @@ struct EpAsmArgs {
     unsigned divM, divS, nWaves, mode;      // mode: 1 the fused trip, 0 the phase-voting loop
     void* dbg;                      // developer builds of the assembly (-DPT_ASM_DEBUG): 32 B per wave
     const void* ellip; int numEllip, nodeStride;      // EllipRec array (rotation matrices by k_frame_setup); bytes per node record (80 or 64)
-    int groupShift, pad0;           // more than 8 BVHs: log2 of the objects per group box (the 64 group boxes follow the root records)
+    int groupShift, stackDepth;     // more than 8 BVHs: log2 of the objects per group box (the 64 group boxes follow the root records); levels of the traversal stacks (24-bit entries: where the byte array starts)
     void* HX;                       // State::HX of scenes whose ellipsoids carry texture-mapped materials, else null
 };
 static_assert(sizeof(EpAsmArgs) == 152 && offsetof(EpAsmArgs, HX) == 144 && offsetof(EpAsmArgs, ellip) == 120 && offsetof(EpAsmArgs, groupShift) == 136, "EpAsmArgs layout is part of the assembly");
@@ -1349,9 +1349,9 @@ static_assert(sizeof(EllipRec) == 128 && offsetof(EllipRec, rotated) == 32 && of
 int loadAsmKernel(pt_ctx* c, int k) {
     if (c->asmFn[k]) return 0;
     if (!c->asmLoadError[k].empty()) return fail(PT_ERR_HIP, c->asmLoadError[k]);
-    const void* images[12] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f,
-                              pt_extend_hsaco_s16w, pt_extend_hsaco_p18w, pt_extend_hsaco_s16fw, pt_extend_hsaco_p18fw,
-                              pt_extend_hsaco_s16h, pt_extend_hsaco_p18h, pt_extend_hsaco_s16fh, pt_extend_hsaco_p18fh};
+    const void* images[18] = {pt_extend_hsaco_s16, pt_extend_hsaco_p18, pt_extend_hsaco_s16f, pt_extend_hsaco_p18f, pt_extend_hsaco_p24, pt_extend_hsaco_p24f,
+                              pt_extend_hsaco_s16w, pt_extend_hsaco_p18w, pt_extend_hsaco_s16fw, pt_extend_hsaco_p18fw, pt_extend_hsaco_p24w, pt_extend_hsaco_p24fw,
+                              pt_extend_hsaco_s16h, pt_extend_hsaco_p18h, pt_extend_hsaco_s16fh, pt_extend_hsaco_p18fh, pt_extend_hsaco_p24h, pt_extend_hsaco_p24fh};
     hipModule_t m = nullptr; hipFunction_t f = nullptr;
     hipError_t e = hipModuleLoadData(&m, images[k]);
     if (e == hipSuccess) e = hipModuleGetFunction(&f, m, "pt_extend_asm");
@@ -1375,12 +1375,13 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // shading blocks: 1024-thread blocks -4...7 %), and so they do for a launch too small to give every CU its two large blocks.
     const bool sharedGpu = c->streamsOnDevice > 1;
     const bool lazyRoots = sc.numObj > 8;                      // more than 8 BVHs: root records in LDS, tested when a BVH's turn comes (no per-lane distances)
-    const size_t perLane = (lazyRoots ? 0 : (size_t)sc.numObj * 4) + (size_t)c->stackDepth * 2;      // root-box distances + traversal stack of one lane
+    const size_t entryBytes = c->stackMode == 2 ? 3 : 2;       // traversal-stack entry in LDS: 16 bits (+ 2 in registers: Packed18), or 16 + 8 (24-bit entries)
+    const size_t perLane = (lazyRoots ? 0 : (size_t)sc.numObj * 4) + (size_t)c->stackDepth * entryBytes;      // root-box distances + traversal stack of one lane
     const size_t rootBytes = lazyRoots ? ((size_t)sc.numObj + 64) * 32 : 0;      // the root records and the 64 group boxes of the per-ray cull (buildScene)
     const bool largeFits = 2 * (perLane * 1024 + rootBytes + 48 + 16384) <= (size_t)160 * 1024;      // two large blocks per CU with at least a 16 KB tile each (deep trees: stacks)
     const int TPB = c->asmTpb ? c->asmTpb : (!sharedGpu && largeFits && pr.launched >= (uint64_t)c->numCUs * 2048 ? 1024 : 256);
     const int BPW = TPB / 256;                                  // how many 256-thread blocks one block stands for
-    const size_t fixed = (lazyRoots ? rootBytes : (size_t)sc.numObj * 4 * TPB) + 48 + (size_t)c->stackDepth * 2 * TPB;      // root-box distances (or root records), root references + ray cursor, traversal stacks
+    const size_t fixed = (lazyRoots ? rootBytes : (size_t)sc.numObj * 4 * TPB) + 48 + (size_t)c->stackDepth * entryBytes * TPB;      // root-box distances (or root records), root references + ray cursor, traversal stacks
     const size_t ldsPerCU = 160 * 1024;                        // gfx950; one block may take all of it
     if (fixed + 2048 > ldsPerCU) return false;
     // Blocks per CU and tile: alone on the GPU the kernel wants every wave slot (8 blocks of 256 threads, 8 KB tile).  When the context's streams
@@ -1406,11 +1407,12 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     int perCU = std::max(1, std::min((int)(ldsPerCU / lds), maxBlocks));
     int grid = c->numCUs * perCU;
     grid = std::max(1, std::min(grid, ((int)pr.launched + TPB - 1) / TPB));
-    const int variant = (c->stackMode == 1 ? 1 : 0) + (c->streamFast && !c->debugExactExtend ? 2 : 0) + (TPB == 1024 ? 4 : TPB == 512 ? 8 : 0);
+    const bool fastRcp = c->streamFast && !c->debugExactExtend;
+    const int variant = (c->stackMode == 2 ? (fastRcp ? 5 : 4) : (c->stackMode == 1 ? 1 : 0) + (fastRcp ? 2 : 0)) + (TPB == 1024 ? 6 : TPB == 512 ? 12 : 0);
     if (loadAsmKernel(c, variant)) { c->asmError = "hand-written intersect kernel: " + g_err; return false; }      // loud: pump() fails, no silent fallback
     a.nodes80 = c->dNodes80; a.tris = c->dTris; a.roots = c->dRoots; a.G0 = pr.st.G0; a.G1 = pr.st.G1; a.H = pr.st.H;
     a.queue = c->dQueue[pr.iter & 1]; a.ctl = c->dCtl;
-    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride; a.groupShift = c->asmGroupShift; a.HX = c->ellipMaps ? (void*)pr.st.HX : nullptr;
+    a.ellip = c->dEllip; a.numEllip = sc.numEllip; a.nodeStride = c->asmNodeStride; a.groupShift = c->asmGroupShift; a.stackDepth = c->stackDepth; a.HX = c->ellipMaps ? (void*)pr.st.HX : nullptr;
     a.numObj = sc.numObj; a.iter = pr.iter; a.nSlots = (int)pr.launched; a.refillMin = c->refillMin; a.keepEighths = c->innerKeepEighths; a.noneMin = c->noneMin;
     // main loop: the fused trip with fetch-at-decision, unless the whole scene sits in the LDS tile — then no fetch is worth hiding and the
     // phase-voting loop's fewer instructions per ray win (C2: 3.4 against 3.1 Gsamples/s, profiles/r03_c_*)

@@ -2,7 +2,7 @@
 """What the launches that the hand-written intersect kernel does not take cost (they run the compiled k_extend_persist, same results): Msamples/s of
   C4 on the hand-written kernel and forced onto the compiled one (the price of the fall-back on a scene both take),
   C3 and C5 with RAYTRACING = 0 (directDiffuse; C5: with the thickness probes of its subsurface materials),
-  a one-object height field of ~1 M triangles (2 M nodes: beyond the 18-bit traversal-stack entries of the hand-written kernel),
+  a one-object height field of ~1 M triangles (2 M nodes: 24-bit traversal-stack entries; until round 5 such trees ran the compiled kernel) on both kernels,
 each 1920x1080, two streams on GPU 0, synchronous batches of 8 frames x SAMPLE_RES 8."""
 import os
 import sys
@@ -52,3 +52,4 @@ sc.use_gpu_bvh_builder(0)
 sc.addObjectText(obj_text(v, f).encode(), 0)
 big = scenes._finish("big", sc, W, H, (0.0, 0.8, -1.6), (0.35, 0.0, 0.0), (150, 180, 230), 8, 8)
 run(f"height field, {len(f)} triangles / {big.info['nodes']} nodes, 8 bounces", big)
+run("... forced onto the compiled kernel (extend_mode 1)", big, extend_mode=1)

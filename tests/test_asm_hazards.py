@@ -77,7 +77,7 @@ def test_product_code_objects_are_hazard_free(pt):
     build.assemble_extend()
     d = os.path.join(ROOT, "build", "asm", "pt_extend_hsaco")
     objs = sorted(f for f in os.listdir(d) if f.endswith(".hsaco"))
-    assert len(objs) == 12
+    assert len(objs) == 18
     for f in objs:
         n, found, waived = _checker().scan(os.path.join(d, f), waive=True)
         assert n > 1000 and not found, (f, found[:5])

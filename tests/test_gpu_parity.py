@@ -253,6 +253,9 @@ def mixed_regular_and_axis_parallel_rays(wl, n, seed):
                                               ("C6", 64, 36, {}, {"asm_root_cull": 0}), ("C6", 64, 36, {"groups": 70, "nu": 6, "nv": 6}, {}),
                                               ("C6", 64, 36, {"groups": 130, "nu": 4, "nv": 4}, {"asm_loop": 0, "refill_min": 1}), ("C6", 64, 36, {"groups": 600, "nu": 4, "nv": 4}, {"asm_tpb": 1024}),
                                               ("C6", 64, 36, {"groups": 65, "nu": 4, "nv": 4}, {"asm_node_layout": 1, "none_min": 1}),
+                                              # 24-bit traversal-stack entries (16 bits + a byte in a second LDS array: what trees beyond 131071 nodes get), forced onto small trees
+                                              ("C3", 96, 54, {}, {"stack_mode": 2}), ("C4", 64, 36, {}, {"stack_mode": 2, "asm_loop": 0}), ("C5", 64, 36, {}, {"stack_mode": 2, "asm_tpb": 1024}),
+                                              ("C6", 64, 36, {}, {"stack_mode": 2, "refill_min": 1}),
                                               # 512-thread blocks
                                               ("C3", 96, 54, {}, {"asm_tpb": 512}), ("C4", 64, 36, {}, {"asm_tpb": 512, "asm_loop": 0}), ("C6", 64, 36, {}, {"asm_tpb": 512, "refill_min": 8})])
 def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W, H, kw, opts):
@@ -334,6 +337,7 @@ def test_root_cull_only_where_the_boxes_promise_it(pt, renderer_mod, perturb):
                                                      ("C3", 128, 72, 3, {}, {"asm_tpb": 1024}), ("C3", 128, 72, 3, {}, {"asm_tpb": 1024, "path_slots": 2048}),
                                                      ("C4", 64, 36, 2, {}, {"asm_tpb": 1024}), ("C5", 64, 36, 2, {"subdiv": 2}, {"asm_tpb": 1024}),
                                                      ("C1", 96, 96, 3, {}, {}), ("C6", 96, 54, 2, {}, {}), ("C6", 96, 54, 2, {}, {"asm_tpb": 1024, "path_slots": 2048}),
+                                                     ("C3", 128, 72, 3, {}, {"stack_mode": 2}), ("C4", 64, 36, 2, {}, {"stack_mode": 2, "path_slots": 2048}),
                                                      ("C6", 96, 54, 2, {"groups": 70, "nu": 6, "nv": 6}, {}), ("C6", 96, 54, 2, {"groups": 200, "nu": 4, "nv": 4}, {"path_slots": 2048})])
 def test_render_parity_handwritten_kernel(pt, oracle, renderer_mod, name, W, H, frames, kw, opts):
     """whole renders on the hand-written intersect kernel (statistics off: the counting variant is the compiled kernel) against the oracle,
