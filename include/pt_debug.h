@@ -14,7 +14,7 @@ extern "C" {
  * backlog up to 2^23 for overlapped batches), 1 = count traversal statistics (0/1), 2 = LDS bytes per block of the simple intersect
  * kernel, 3 = lanes of a wave waiting for their next BVH / retirement that make that phase worth a trip (default 8, 2 in the fused loop of the hand-written kernel; 1 = at once),
  * 4 = intersect kernel (0 simple, one block per 256 rays; 1 persistent blocks, compiled; 2 = default: the hand-written form of 1, csrc/hip/pt_extend_gfx950.s,
- *     for the launches it takes — at most 1024 BVHs, no empty leaves, ordered boxes, fewer than 2^23 - 1 inner nodes / triangle records, no thickness probes (RAYTRACING == 1, or RAYTRACING == 0 without subsurface materials), statistics off — and 1 for the others),
+ *     for the launches it takes — at most 1024 BVHs, no empty leaves, ordered boxes, fewer than 2^23 - 1 inner nodes / triangle records, statistics off — and 1 for the others),
  * 5 = persistent block size (64/128/256/512/1024, default 256), 6 = persistent LDS tile bytes, 7 = idle lanes per wave that trigger a ray refill,
  * 8 = cap on the blocks per CU of the persistent grid (default 0 = no cap: as many as are resident at once, 8 blocks of 256 threads = 8 waves per SIMD),
  * 9 = the inner-node phase repeats while more than this many eighths of its starting lanes still sit on inner nodes (default 6),

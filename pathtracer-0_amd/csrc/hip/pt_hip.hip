@@ -1366,9 +1366,9 @@ int loadAsmKernel(pt_ctx* c, int k) {
 
 // true: launched.  false: this launch is not one the hand-written kernel takes (the caller uses the compiled kernel)
 bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
-    // (RAYTRACING == 0, directDiffuse: its rays are ordinary rayScene calls — except the thickness probes of subsurface materials (FL_PROBE: no offset, one BVH, no
-    //  ellipsoids), which only the compiled kernel traces; a scene without such a material never makes one)
-    if (!c->asmEligible || c->countStats || (c->streamIn.params[9] != 1.0f && c->anySubsurface) || c->extendTpb != 256) return false;
+    // (RAYTRACING == 0, directDiffuse: its rays are ordinary rayScene calls, and the thickness probes of subsurface materials — FL_PROBE: no offset, one BVH, no
+    //  ellipsoids — are set up at the kernel's refill)
+    if (!c->asmEligible || c->countStats || c->extendTpb != 256) return false;
     const DevScene& sc = c->sc;
     // Block size.  What bounds this kernel is its CU's instruction issue and vector-memory pipe together (profiles/r03_h_*): node steps served from
     // the LDS tile cost neither a tag lookup nor a round trip, and the tile is per BLOCK — the same bytes eight times over with 256-thread blocks.

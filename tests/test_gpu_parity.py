@@ -962,8 +962,8 @@ def test_n2_direct_diffuse_mode(pt, oracle, renderer_mod, name, mode):
         m[1 + 48 + 43 - 1: 1 + 48 + 46 - 1] = [0.4, 0.8, 0.5]; m[1 + 48 + 46 - 1: 1 + 48 + 49 - 1] = [1, 1, 1]
         b[14] = m
         wl = pt.scenes.Workload(wl.name, wl.W, wl.H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
-    # (a scene without subsurface materials makes no thickness probes: its directDiffuse rays are ordinary rayScene calls and run on the hand-written kernel)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, extend_mode=mode, expect_asm=(mode == 2 and name in ("C3", "C2", "C6")))
+    # (round 5: directDiffuse runs on the hand-written intersect kernel, thickness probes included: FL_PROBE rays are set up at its refill)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 2, extend_mode=mode, expect_asm=(mode == 2))
     assert_same(got, ref, cnt, ocnt)
     assert cnt["segments"] == cnt["samples"]
 
@@ -1213,7 +1213,7 @@ def test_random_scenes(pt, oracle, renderer_mod, seed):
     got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, wl, 3, index_stack_8bit=seed % 3)      # the three encodings of the index stack in the path state (3-bit / 8-bit codes, floats)
     assert_same(got, ref, cnt, ocnt)
     direct = wl.with_params(RAYTRACING=0)
-    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, direct, 2, extend_mode=seed % 2)
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, direct, 2, extend_mode=(2 if seed % 3 == 0 else seed % 2))      # (2: thickness probes on the hand-written kernel)
     assert_same(got, ref, cnt, ocnt)
 
 
