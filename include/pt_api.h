@@ -30,8 +30,8 @@ enum {
     PT_ERR_HIP = -3,        /* a HIP runtime call failed */
     PT_ERR_SCENE = -4,      /* scene buffers inconsistent (index out of range, BVH deeper than the
                                reference's int stack[64] (frag.glsl:465), ...) */
-    PT_ERR_UNSUPPORTED = -5 /* feature the reference has but SURVEY.md §2/§8(f) scopes out
-                               (implicit surfaces: dead code in the reference) */
+    PT_ERR_UNSUPPORTED = -5 /* a request outside what this implementation's encodings hold (e.g. directDiffuse with subsurface
+                               materials over more than 65536 BVHs) */
 };
 
 /* SSBO binding points of frag.glsl:14-77 accepted by pt_set_buffer */
@@ -89,7 +89,8 @@ int pt_reset_frame(pt_ctx* ctx);
  * On return the frame is accumulated in FRAME (in stream order on the context's stream).
  * Limits of this implementation where the shader's are its int range (PT_ERR_ARG / PT_ERR_UNSUPPORTED / PT_ERR_SCENE otherwise):
  * SAMPLE_RES <= 2047, MAX_BOUNCES <= 4095, pixels * frames of a batch < 2^31, BVH depth <= 64 (the shader's own `int stack[64]`,
- * frag.glsl:465), texture indices <= 4095, no implicit surfaces (dead code in the reference). */
+ * frag.glsl:465), texture indices <= 4095.  Implicit surfaces (binding 5) are accepted and, as in the reference — rayImplicit returns 1e30 before anything
+ * else, frag.glsl:385-386 — never hit. */
 int pt_render(pt_ctx* ctx, int frame_count, int seed);
 /* n_frames consecutive frames (u_frameCount = first_frame .. first_frame+n_frames-1, u_seed =
  * seeds[i]) rendered as ONE wavefront batch; FRAME is accumulated in frame order, so the result

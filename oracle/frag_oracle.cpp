@@ -350,7 +350,8 @@ Hit rayScene(Ctx& c, vec3 o, vec3 d) {
     }
     if (btri >= 0) triShading(c, btri, bu, bv, N, uvx, uvy, hitMat);
     // implicits (frag.glsl:578-605): rayImplicit returns 1e30 unconditionally (:385-386); the
-    // test `t < closest_t` can then only pass when closest_t > 1e30, i.e. never.
+    // test `t < closest_t` can then only pass when closest_t > 1e30, i.e. never: whatever
+    // ImpData holds, the loop changes nothing and draws no random number.
     const float* E = s->ellip; int n = c.numEllipsoids;
     for (int i = 0; i < n; i++) {
         vec3 cc = v3(E[1 + 3 * i], E[1 + 3 * i + 1], E[1 + 3 * i + 2]);
@@ -620,7 +621,7 @@ int setupCtx(Ctx& c, const orc_scene* s) {
     c.numEllipsoids = (int)s->ellip[0];
     c.camRot = rotationMatrix(c.ROTATION);
     c.count = true;
-    if (c.numImplicits != 0) return -3;                          // implicits are dead code in the reference
+    if (c.numImplicits < 0) return -3;                           // (implicits: looped over and never hit, see intersectScene)
     int nm = c.me > 0 ? (int)((s->n_mtl_floats - 1) / c.me) : 0;
     for (int m = 0; m < nm; m++) {                               // every texture a material names must have been uploaded
         Mtl t = newMtl(c, m);

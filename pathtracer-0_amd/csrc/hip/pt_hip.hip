@@ -979,7 +979,9 @@ int buildScene(pt_ctx* c) {
     if (c->mouse.size() < 3) return fail(PT_ERR_SCENE, "MOUSE_POS (binding 2) not set");
     if (c->mtl.empty()) return fail(PT_ERR_SCENE, "mtlData (binding 14) not set");
     if (c->objidx.empty()) return fail(PT_ERR_SCENE, "objIndices (binding 13) not set");
-    if (c->imp.empty() || (int)c->imp[0] != 0) return fail(PT_ERR_UNSUPPORTED, "implicit surfaces are dead code in the reference (rayImplicit returns 1e30, frag.glsl:385-386): send ImpData = [0]");
+    // Implicit surfaces: the reference loops over them (frag.glsl:578-605) and rayImplicit returns 1e30 before anything else (:385-386), so `t < closest_t` never passes —
+    // they are never hit and leave no trace in the image.  The buffer is accepted as the reference's scene code sends it (dispatch.java:429-456) and otherwise unread.
+    if (c->imp.empty() || !(c->imp[0] >= 0.0f)) return fail(PT_ERR_SCENE, "ImpData (binding 5) not set: [count, fn x n, shift x 3n, scale x 3n, rot x 3n, mat x n]; send [0] for none");
     if (c->ellip.empty()) return fail(PT_ERR_SCENE, "EllipData (binding 7) not set");
     if (c->sky.empty()) return fail(PT_ERR_SCENE, "texture 0 (sky) not set");
     if (c->bvhdata.size() < 8 * nNodes) return fail(PT_ERR_SCENE, "BVHdata shorter than 8 floats per BVHtree node");

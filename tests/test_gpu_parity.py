@@ -292,6 +292,31 @@ def test_handwritten_intersect_kernel_equals_compiled(pt, renderer_mod, name, W,
     assert (out[2][1] >= 0).sum() > 1000
 
 
+def test_implicit_surfaces_are_accepted_and_never_hit(pt, oracle, renderer_mod):
+    """scene.addImplicit (dispatch.java:1005-1011) fills binding 5; the shader loops over the implicits (frag.glsl:578-605) but rayImplicit returns 1e30 before anything
+    else (:385-386), so they are never hit: a scene WITH implicits renders the image of the scene without them — here and in the oracle, which both used to refuse it"""
+    W, H = 96, 54
+
+    def build(with_implicits):
+        sc = pt.hostlib.Scene()
+        sc.addMaterial("default"); sc.setLastMtl("Kd", (0.8, 0.8, 0.8)); sc.setLastMtl("Pr", 1)
+        sc.addMaterial("lamp"); sc.setLastMtl("Ke", (12, 12, 12))
+        quad = ("o floor\nvn 0 1 0\nv -2 0 -2\nv 2 0 -2\nv 2 0 2\nv -2 0 2\nf 1//1 2//1 3//1\nf 1//1 3//1 4//1\n"
+                "o lamp\nusemtl lamp\nvn 0 -1 0\nv -0.5 2 -0.5\nv 0.5 2 -0.5\nv 0.5 2 0.5\nv -0.5 2 0.5\nf 5//2 7//2 6//2\nf 5//2 8//2 7//2\n")
+        sc.addObjectText(quad, 0, parentDirectory="")
+        sc.addEllipsoid((0.0, 0.5, 0.0), 1.0, 0.0, 0.5, 0)
+        if with_implicits:
+            sc.addImplicit(2, (0.0, 0.6, 0.0), (0.5, 0.5, 0.5), (0.0, 0.0, 0.0), 1)
+            sc.addImplicit(0, (0.3, 0.2, -0.4), (1.0, 2.0, 1.0), (0.2, 0.1, 0.0), 0)
+        return pt.scenes._finish("implicits", sc, W, H, (0.0, 1.0, -3.0), (0.0, 0.0, 0.0), (150, 180, 230), 8, 4)
+    with_i, without = build(True), build(False)
+    assert int(with_i.buffers[5][0]) == 2 and int(without.buffers[5][0]) == 0
+    got, ref, cnt, ocnt = render_both(pt, oracle, renderer_mod, with_i, 3)
+    assert_same(got, ref, cnt, ocnt)
+    plain, ref0, _, _ = render_both(pt, oracle, renderer_mod, without, 3)
+    assert np.array_equal(got, plain, equal_nan=True) and np.array_equal(ref, ref0, equal_nan=True)
+
+
 @pytest.mark.parametrize("perturb", ["children_stick_out", "root_box_shrunk_to_nothing", "inverted_root_box"])
 def test_root_cull_only_where_the_boxes_promise_it(pt, renderer_mod, perturb):
     """The per-ray cull of the object loop skips a BVH whose ROOT box the ray misses; that is rayBVH's own result only if the root's child boxes lie inside an
