@@ -554,7 +554,9 @@ __global__ void __launch_bounds__(TPB, PT_EP_WAVES) k_extend_persist(DevScene sc
 // divergence saved: 2-4 % per step on C2-C5, profiles/; likewise the dense LDS-listed pass that used to compute the camera
 // rays of new samples for the whole block.)
 template <int STK, bool STATS, bool DIRECT, bool TEX, bool FAST = false>
-__global__ void __launch_bounds__(SHADE_BLOCK) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
+// (the texture-map variants are asked for 5 waves per SIMD: left alone the compiler spends 104-110 registers on them, 4 waves; at 96 it spills two and a
+//  scene with a map on every material gains 3 %: profiles/r05_k_textured_materials.txt.  The float-stack variant would spill ten: left alone.)
+__global__ void __launch_bounds__(SHADE_BLOCK, (TEX && !STATS && STK != 32) ? 5 : 1) k_shade(DevScene sc, Batch b, const FrameConst* fcp, State st, const unsigned* qIn, unsigned* qOut, int iter,
                                                  int nSlots, Control* ctl) {
     constexpr bool TRANS = STK != 0;
     __shared__ unsigned sCntA[SHADE_BLOCK / 64], sCntB[SHADE_BLOCK / 64], sBase;
