@@ -16,7 +16,9 @@
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
 #include "glsl_math.h"
 
+#include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <cstdio>
 #include <thread>
 #include <vector>
@@ -54,7 +56,10 @@ struct orc_scene {
 // counters: S, Nv, Tt, Hu + extras
 // ... and the shape of the traversal (what a kernel that takes two steps per trip could chain): inner nodes popped; those popped right after their
 // parent's step as its left / its right child (the near child, pushed last); leaves popped right after their parent's step, and those of them that hold one triangle
-enum { C_SEGMENTS = 0, C_NODES, C_TRITESTS, C_HITUPD, C_SAMPLES, C_BOXTESTS, C_RNG, C_ELLIP, C_INNER, C_LEFTNEXT, C_RIGHTNEXT, C_LEAFNEXT, C_LEAFNEXT1, C_N };
+// ... and (round 6) a WHAT-IF pass over the same rays (orc_set_whatif): nodes popped / triangles tested by another order of the object loop, and the rays whose
+// hit record would then differ from the reference's (DESIGN.md "object order")
+enum { C_SEGMENTS = 0, C_NODES, C_TRITESTS, C_HITUPD, C_SAMPLES, C_BOXTESTS, C_RNG, C_ELLIP, C_INNER, C_LEFTNEXT, C_RIGHTNEXT, C_LEAFNEXT, C_LEAFNEXT1,
+       C_XNODES, C_XTRIS, C_XDIFF, C_XPRE, C_N };
 
 }  // extern "C"
 
@@ -334,6 +339,124 @@ void triShading(const Ctx& c, int tri, float u, float v, vec3& norm, float& uvx,
     } else { uvx = -1.0f; uvy = -1.0f; }
 }
 
+
+// ---- what-if statistics (round 6; never part of a rendered value) --------------------------------------------------------------------
+// The object loop of rayScene (:563-577) visits the BVHs in index order.  These restate it in other orders ON THE SAME RAYS and count what a kernel built that
+// way would visit, and how often its hit record would differ from the reference's.
+//   1  nearest root box first; a BVH of lower index than the current winner's is entered with `<=` instead of `<` (bound = nextup(closest_t)) until it produces a hit
+//   2  the same, and while `<=` holds the pushes are pruned against closest_t * (1 + m) (a margin for box distances that round above their triangles')
+//   3  a bounding pre-pass through the BVH of the nearest root box, then the reference's loop with closest_t starting at U = t_pre * (1 + m) (no hit recorded)
+//   4  pre-pass = mode 1 over all BVHs, then the reference's loop from U
+//   5  pre-pass = BVHs nearest root first until one produces a hit, then the reference's loop from U
+//   6  pre-pass = BVHs nearest root first, stopping at the FIRST triangle hit, then the reference's loop from U
+//   7 / 8  mode 1 with only the one / two nearest root boxes taken out of the index order
+int g_whatif = 0;
+float g_whatif_margin = 1.0f / 64.0f;
+
+struct XStat { uint64_t nodes = 0, tris = 0; };
+
+// rayBVH with the acceptance / pruning rule as parameters.  closest: bound; eq: accept t <= closest (and prune by <=) until the first hit of this call; scale: factor on
+// the pruning bound while eq holds; firstHit: return at the first accepted triangle
+BvhResult xBVH(Ctx& c, vec3 o, vec3 d, int top, float closest, bool eq, float scale, bool firstHit, XStat& st) {
+    const orc_scene* s = c.s;
+    BvhResult res{1e30f, 0, 0, -1, false};
+    vec3 invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int stack[64]; int sp = 0;
+    auto pruneBound = [&]() { return eq ? __builtin_nextafterf(closest, __builtin_inff()) * scale : closest; };
+    if (rayBox(o, invD, s->bvhdata + 8 * top) > (eq ? closest * scale : closest)) return res;
+    stack[sp++] = top;
+    while (sp > 0) {
+        int node = stack[--sp];
+        st.nodes++;
+        int left = s->bvhtree[3 * node + 1], right = s->bvhtree[3 * node + 2];
+        if ((left | right) == -1) {
+            int startIdx = (int)s->bvhdata[8 * node + 6], endIdx = (int)s->bvhdata[8 * node + 7];
+            for (int i = startIdx; i < endIdx; i++) {
+                int tri = s->leaf_tris[i];
+                const float* T = s->tris + 40 * (int64_t)tri;
+                float t = 0, u = 0, v = 0;
+                st.tris++;
+                bool ok = rayTri(o, d, v3(T[0], T[1], T[2]), v3(T[4], T[5], T[6]), v3(T[8], T[9], T[10]), t, u, v);
+                float hx = ok ? t : 1e30f;
+                if (hx > 0.0f && (eq ? hx <= closest : hx < closest)) {
+                    closest = hx; eq = false;
+                    res.t = hx; res.u = u; res.v = v; res.id = tri; res.any = true;
+                    if (firstHit) return res;
+                }
+            }
+        } else {
+            float Ld = rayBox(o, invD, s->bvhdata + 8 * (left > 0 ? left : 0));
+            float Rd = rayBox(o, invD, s->bvhdata + 8 * (right > 0 ? right : 0));
+            float pb = pruneBound();
+            if (Ld > Rd) {
+                if (Ld < pb) stack[sp++] = left;
+                if (Rd < pb) stack[sp++] = right;
+            } else {
+                if (Rd < pb) stack[sp++] = right;
+                if (Ld < pb) stack[sp++] = left;
+            }
+        }
+    }
+    return res;
+}
+
+struct XHit { float t; int id; int obj; };
+
+// the BVH part of rayScene in the order `mode` names; o is the offset origin
+XHit xObjectLoop(Ctx& c, vec3 o, vec3 d, int mode, XStat& st, XStat& pre) {
+    const orc_scene* s = c.s;
+    const int n = c.numObj;
+    vec3 invD = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    std::vector<std::pair<float, int>> order;                      // (root entry distance, object), root boxes the ray meets only
+    for (int I = 1; I < n + 1; I++) {
+        float e = rayBox(o, invD, s->bvhdata + 8 * s->obj_indices[I]);
+        if (!(e > 1e29f)) order.push_back({e, I});
+    }
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first < b.first; });
+    const float m = g_whatif_margin;
+    auto nearestFirst = [&](bool margin, bool untilHit, bool firstTri, XStat& S) {
+        XHit h{1e30f, -1, 1 << 30};
+        for (auto& e : order) {
+            int I = e.second;
+            bool eq = h.id >= 0 && I < h.obj;
+            BvhResult r = xBVH(c, o, d, s->obj_indices[I], h.t, eq, (eq && margin) ? 1.0f + m : 1.0f, firstTri, S);
+            if (r.any) { h.t = r.t; h.id = r.id; h.obj = I; if (untilHit || firstTri) break; }
+        }
+        return h;
+    };
+    auto indexOrderFrom = [&](float U) {
+        XHit h{U, -1, -1};
+        for (int I = 1; I < n + 1; I++) {
+            BvhResult r = xBVH(c, o, d, s->obj_indices[I], h.t, false, 1.0f, false, st);
+            if (r.any && r.t < h.t) { h.t = r.t; h.id = r.id; h.obj = I; }
+        }
+        if (h.id < 0) h.t = 1e30f;
+        return h;
+    };
+    if (mode == 9) {                                                // 9: index order over the BVHs whose root box the ray meets (what the per-ray cull leaves today)
+        std::sort(order.begin(), order.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.second < b.second; });
+        return nearestFirst(false, false, false, st);
+    }
+    if (mode == 7 || mode == 8) {                                   // 7 / 8: the one / two nearest root boxes first, the rest in index order
+        size_t k = std::min(order.size(), (size_t)(mode - 6));
+        std::sort(order.begin() + k, order.end(), [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.second < b.second; });
+        return nearestFirst(false, false, false, st);
+    }
+    if (mode == 1) return nearestFirst(false, false, false, st);
+    if (mode == 2) return nearestFirst(true, false, false, st);
+    XHit p{1e30f, -1, -1};
+    if (mode == 3) {
+        if (!order.empty()) {
+            BvhResult r = xBVH(c, o, d, s->obj_indices[order[0].second], 1e30f, false, 1.0f, false, pre);
+            if (r.any) { p.t = r.t; p.id = r.id; }
+        }
+    } else if (mode == 4) p = nearestFirst(false, false, false, pre);
+    else if (mode == 5) p = nearestFirst(false, true, false, pre);
+    else p = nearestFirst(false, false, true, pre);
+    if (p.id < 0 && mode != 3) return XHit{1e30f, -1, -1};          // every BVH the ray meets traversed without a bound and nothing found: the reference finds nothing
+    return indexOrderFrom(p.id >= 0 ? p.t * (1.0f + m) : 1e30f);
+}
+
 // frag.glsl:548-653
 Hit rayScene(Ctx& c, vec3 o, vec3 d) {
     const orc_scene* s = c.s;
@@ -347,6 +470,13 @@ Hit rayScene(Ctx& c, vec3 o, vec3 d) {
         int root = s->obj_indices[I];
         BvhResult r = rayBVH(c, o, d, root, closest_t);
         if (r.any && r.t < closest_t) { closest_t = r.t; hitType = 1; hitID = r.id; btri = r.id; bu = r.u; bv = r.v; parentID = root; }
+    }
+    if (g_whatif && c.count) {
+        XStat st, pre;
+        XHit x = xObjectLoop(c, o, d, g_whatif, st, pre);
+        c.cnt[C_XNODES] += st.nodes + pre.nodes; c.cnt[C_XTRIS] += st.tris + pre.tris; c.cnt[C_XPRE] += pre.nodes;
+        float rt = btri >= 0 ? closest_t : 1e30f;
+        if (x.id != btri || std::memcmp(&x.t, &rt, 4) != 0) c.cnt[C_XDIFF]++;
     }
     if (btri >= 0) triShading(c, btri, bu, bv, N, uvx, uvy, hitMat);
     // implicits (frag.glsl:578-605): rayImplicit returns 1e30 unconditionally (:385-386); the
@@ -756,6 +886,9 @@ void orc_display(const float* frame, int W, int H, int frameCount, int java_byte
         }
     }
 }
+
+// what-if statistics of the object loop (0 = off); see xObjectLoop
+void orc_set_whatif(int mode, float margin) { g_whatif = mode; g_whatif_margin = margin; }
 
 int orc_has_fma(void) { return __builtin_cpu_supports("fma") ? 1 : 0; }
 

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
-COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "rng", "ellip", "inner", "leftnext", "rightnext", "leafnext", "leafnext1"]
+COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "rng", "ellip", "inner", "leftnext", "rightnext", "leafnext", "leafnext1", "xnodes", "xtris", "xdiff", "xpre"]
 
 
 class _Scene(C.Structure):
@@ -39,6 +39,7 @@ def lib():
         L.orc_rng.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_set_whatif.argtypes = [C.c_int, C.c_float]
         L.orc_display.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         if not L.orc_has_fma():
             raise RuntimeError("oracle needs a CPU with FMA (built with -mfma)")
@@ -142,3 +143,8 @@ def display(frame, frame_count, java_bytes=True):
     out = np.zeros((H, W, 3), dtype=np.uint8)
     lib().orc_display(f.ctypes.data, W, H, int(frame_count), 1 if java_bytes else 0, out.ctypes.data)
     return out
+
+
+def set_whatif(mode, margin=1.0 / 64):
+    """statistics only: count what another order of rayScene's object loop would visit on the same rays (frag_oracle.cpp: xObjectLoop); 0 = off"""
+    lib().orc_set_whatif(int(mode), float(margin))

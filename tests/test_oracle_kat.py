@@ -291,3 +291,44 @@ def test_unorm8_reciprocal_form(tmp_path):
     exe = tmp_path / "u"
     subprocess.check_call(["gcc", "-O0", "-ffp-contract=off", str(src), "-o", str(exe), "-lm"])
     assert subprocess.check_output([str(exe)], text=True).split() == ["0", "0"]
+
+
+# ------------------------------------------------------------------------------------------ object order (round 6; statistics of the oracle, no rendered value)
+def _duplicate_wall_workload(pt, order):
+    """two `o` groups that hold the SAME wall (coplanar identical triangles, coordinates that are not dyadic so that box and triangle distances round
+    apart); group B also holds a small quad nearer to the camera, so B's root box is met first"""
+    scenes = pt.scenes
+    sc = scenes._new_scene(); scenes._cornell_materials(sc)
+    o = scenes.Obj()
+    wall = ((-1.1, 0.05, 0.93), (0.9, 0.05, 0.93), (0.9, 1.9, 0.93), (-1.1, 1.9, 0.93), (0, 0, -1))
+    for g in order:
+        o.group("wall" + g); o.usemtl("white" if g == "A" else "red"); o.quad(*wall)
+        if g == "B":
+            o.quad((0.9, 0, 0), (1, 0, 0), (1, 0.1, 0), (0.9, 0.1, 0), (0, 0, -1))
+    sc.addObjectText(o.text(), 0, parentDirectory="")
+    return scenes._finish("dup", sc, 96, 54, scenes.CORNELL_CAM, scenes.CORNELL_ROT, (10, 20, 30), 8, 4)
+
+
+def test_object_order_whatif(pt, oracle):
+    """rayScene's object loop (frag.glsl:563-577) restated in other orders on the same rays (frag_oracle.cpp: xObjectLoop; profiles/r06_a_object_order_whatif.txt).
+    Pins the two findings the kernel's order rests on: (1) index order over the root boxes a ray meets reproduces the reference's hit records and is what the
+    oracle's node counter minus the pops of missed roots says; (2) `nearest root first, <= for a BVH of lower index than the winner` is NOT the reference on
+    exact ties: a box distance rounds above its own triangle's t, so the lower-index twin is pruned — a margin on the pruning bound or a bounding pre-pass is."""
+    def diffs(wl, mode):
+        oracle.set_whatif(mode)
+        try:
+            _, cnt = oracle.render(oracle.Scene.from_workload(wl), wl.W, wl.H, 1, 1234)
+        finally:
+            oracle.set_whatif(0)
+        c = dict(zip(oracle.COUNTERS, [int(v) for v in cnt]))
+        return c
+    c6 = pt.scenes.build("C6", 96, 54)
+    base = diffs(c6, 9)
+    assert base["xdiff"] == 0 and base["xnodes"] < base["nodes"] and base["xtris"] == base["tritests"]
+    near = diffs(c6, 1)
+    assert near["xdiff"] == 0 and 0.90 * base["xnodes"] < near["xnodes"] < base["xnodes"]        # the whole benefit of the other order on C6: 6 % of the visits
+    ab, ba = _duplicate_wall_workload(pt, "AB"), _duplicate_wall_workload(pt, "BA")
+    assert diffs(ab, 1)["xdiff"] > 100                     # the rule as proposed loses the lower-index twin on a few per cent of the rays ...
+    assert diffs(ba, 1)["xdiff"] == 0
+    for mode in (2, 5, 9):                                # ... the margin and the pre-pass forms do not
+        assert diffs(ab, mode)["xdiff"] == 0 and diffs(ba, mode)["xdiff"] == 0
