@@ -39,6 +39,7 @@ try:
 except Exception:
     METRIC = "Msamples/sec (whole node) at 1920×1080×8-bounce; per-pixel RMSE vs ref"
 HBM_PEAK_GBS = 8000.0                      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+UNIT_PEAK_GCYC = 256 * 2.4                 # busy cycles/ns of a per-CU unit of the vector-memory path (TA, TD) summed over the chip: 256 CUs x 2.4 GHz = 614.4 G/s
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2        # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles each = 1228.8 G/s
 Q_EXTEND = 44                              # algorithmic queue bytes per segment in the intersect kernel: read O,D (24) + write hit record (20), SURVEY.md §8(d)
 
@@ -151,27 +152,47 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     have_hbm = bool(ke and ks and "hbm_bytes_per_segment" in ke and "hbm_bytes_per_segment" in ks)
     ginst = ke["valu_per_segment"] * seg_rate / 1e9 if have_valu else None
     hbm_gbs = (ke["hbm_bytes_per_segment"] + ks["hbm_bytes_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9 if have_hbm else None
-    out = {"bound": "valu_issue", "kernel": ext_kernel, "configuration": f"the timed region: {streams} stream(s) per GPU, {n_gpus} GPU(s)",
-           "achieved": round(ginst, 1) if have_valu else None, "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": round(ginst / VALU_PEAK_GINST, 4) if have_valu else None,
+    # Top level (round 6): the CU's vector-memory path for divergent fetches — what DESIGN.md section 7.1 finds binding — measured as the busy share of the
+    # data-return unit (TD, the busier of the path's two units): TD_TD_BUSY_sum per segment (committed rocprofv3 summary) x the live segment rate of the timed
+    # region, over 256 units x 2.4 GHz.  VALU issue (rounds 2-5's top level) stays as the sub-block `valu_issue`.
+    have_vmem = bool(ke and "td_busy_cycles_per_segment" in ke)
+    unit_gc = UNIT_PEAK_GCYC
+    td = ke["td_busy_cycles_per_segment"] * seg_rate / 1e9 if have_vmem else None
+    ta = ke["ta_busy_cycles_per_segment"] * seg_rate / 1e9 if (ke and "ta_busy_cycles_per_segment" in ke) else None
+    ok = have_vmem and not stale
+    out = {"bound": "vmem_divergent", "kernel": ext_kernel, "configuration": f"the timed region: {streams} stream(s) per GPU, {n_gpus} GPU(s)",
+           "achieved": round(td, 1) if ok else None, "peak": unit_gc, "unit": "G TD-busy cycles/s", "frac": round(td / unit_gc, 4) if ok else None,
            "traffic": round(ke["hbm_bytes_per_segment"] * seg_per_launch) if ke and "hbm_bytes_per_segment" in ke else None,
-           "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if have_hbm else None,
+           "hbm_frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if (have_hbm and not stale) else None,
            "segments_per_launch": round(seg_per_launch), "avg_launch_ms": round(avg_ext, 4), "median_launch_ms": round(r.kernel_time_median("extend"), 4), "launches": n_ext,
            "extend_share_of_step": round(ms_ext / max(world, 1) / (dt * 1e3), 3), "streams_per_gpu": streams,
            "counters_stale": bool(stale), "kernel_source_hash": src_hash, "counters_from": prof_name if prof else None,
            "segments_per_sample": round(S, 3), "per_segment": {"nodes": round(nv, 3), "tritests": round(tt, 3), "hitupd": round(hu, 3)},
-           "note": ("bound = what the dominant kernel sits under: vector-instruction issue (its records come from LDS / L1 / L2, it moves 0.06 of the HBM peak).  achieved = SQ_INSTS_VALU per "
-                    "segment (committed rocprofv3 summary) x segments per launch / mean launch duration of the timed region (HIP events on the launch streams); peak = 256 CUs x 4 SIMDs x 2.4 GHz "
-                    "/ 2 cycles per wave64 instruction.  hbm_frac = rocprofv3 HBM bytes of both kernels over the wall time / 8 TB/s (block `hbm`).  SURVEY.md 8(d)'s algorithmic bytes are under "
-                    "`algorithmic`: priced in the reference's layout, they never reach HBM for a cache-resident tree and carry no fraction.")}
+           "note": ("bound = the resource the dominant kernel saturates: its CU's vector-memory path for divergent node / triangle fetches (DESIGN.md 7.1: launch time flat from 4 waves "
+                    "per SIMD, extra bytes per fetch cost what they weigh).  achieved = TD_TD_BUSY_sum per segment (data-return unit, the busier of the path's two units; committed "
+                    "rocprofv3 summary, each --pmc set in a pass of its own) x segments per launch / mean launch duration of the timed region (HIP events on the launch streams); peak = 256 "
+                    "units x 2.4 GHz.  `vmem` has both units, the tag lookups per vector-memory instruction and the L1 hit rate; `valu_issue` the vector-instruction issue rate against "
+                    "256 CUs x 4 SIMDs x 2.4 GHz / 2; hbm_frac = rocprofv3 HBM bytes of both kernels over the wall time / 8 TB/s (block `hbm`).  SURVEY.md 8(d)'s algorithmic bytes are "
+                    "under `algorithmic`: priced in the reference's layout, they never reach HBM for a cache-resident tree and carry no fraction.")}
+    if stale:
+        out["note"] = ("COUNTERS STALE: " + prof_name + " was measured on other kernel sources (its hash differs from kernel_source_hash): every figure derived from it — frac, "
+                       "hbm_frac, the sub-blocks' fractions — is withheld or provisional until scripts/pmc_all.sh has run on this tree.  ") + out["note"]
+    if have_vmem:
+        out["vmem"] = {"td_busy": {"cycles_per_segment": ke["td_busy_cycles_per_segment"], "achieved": round(td, 1), "frac": round(td / unit_gc, 4)},
+                       "ta_busy": ({"cycles_per_segment": ke["ta_busy_cycles_per_segment"], "achieved": round(ta, 1), "frac": round(ta / unit_gc, 4)} if ta is not None else None),
+                       "alone_on_the_chip": {k: ke.get(k) for k in ("ta_busy_frac_alone", "td_busy_frac_alone", "td_waiting_for_cache_frac_alone", "ta_addr_stalled_by_cache_frac_alone")},
+                       "tag_lookups_per_vmem_inst": ke.get("tag_lookups_per_vmem_inst"), "l1_hit_rate": ke.get("l1_hit_rate"), "l2_round_trip_cycles": ke.get("l2_round_trip_cycles"),
+                       "vmem_rd_per_segment": ke.get("vmem_rd_per_segment"), "provisional": bool(stale)}
+    else:
+        out["note"] = f"no vector-memory counters in {prof_name}: run scripts/pmc_all.sh on a GPU box.  " + out["note"]
     if have_valu:
-        out.update({"valu_insts_per_segment": ke["valu_per_segment"], "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"), "wait_share": ke.get("wait_share"),
-                    "issue_stall_share": ke.get("issue_stall_share")})
+        out["valu_issue"] = {"achieved": round(ginst, 1), "peak": VALU_PEAK_GINST, "unit": "Ginst/s", "frac": round(ginst / VALU_PEAK_GINST, 4), "provisional": bool(stale),
+                             "valu_insts_per_segment": ke["valu_per_segment"], "salu_insts_per_segment": ke.get("salu_per_segment"), "lane_util": ke.get("lane_util"),
+                             "wait_share": ke.get("wait_share"), "issue_stall_share": ke.get("issue_stall_share")}
         if ks and "valu_per_segment" in ks:
             v = (ke["valu_per_segment"] + ks["valu_per_segment"]) * seg / dt / max(n_gpus, 1) / 1e9
             out["chip_valu_issue"] = {"achieved": round(v, 1), "frac": round(v / VALU_PEAK_GINST, 4), "kernel_concurrency": round((ms_ext + ms_sh) / (dt * 1e3) / max(n_gpus, 1), 3),
                                       "note": "both kernels' vector instructions over the wall time of the timed region, per GPU"}
-    else:
-        out["note"] = f"no counter summary in {prof_name}: run scripts/pmc_all.sh on a GPU box.  " + out["note"]
     # ---- measured HBM bytes (north_star: rocprof achieved HBM GB/s against the chip's 8 TB/s), in the contract's form
     hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "note": "rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE (gfx950 correction) per segment from the committed counter summary x the segments of the timed region: both kernels over the "
@@ -195,6 +216,8 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
               "algorithmic_GBps": round(b_ext * rate / 1e9, 1)}
         if have_valu:
             al["valu_issue"] = {"achieved": round(ke["valu_per_segment"] * rate / 1e9, 1), "frac": round(ke["valu_per_segment"] * rate / 1e9 / VALU_PEAK_GINST, 4)}
+        if have_vmem:
+            al["td_busy"] = {"achieved": round(ke["td_busy_cycles_per_segment"] * rate / 1e9, 1), "frac": round(ke["td_busy_cycles_per_segment"] * rate / 1e9 / UNIT_PEAK_GCYC, 4)}
         if ke and "hbm_bytes_per_segment" in ke:
             al["hbm"] = {"achieved": round(ke["hbm_bytes_per_segment"] * rate / 1e9, 1), "frac": round(ke["hbm_bytes_per_segment"] * rate / 1e9 / HBM_PEAK_GBS, 4)}
         if alone.get("avg_shade_ms", 0) > 0:
@@ -483,7 +506,7 @@ def main():
             alone = {"avg_ext_ms": msa / max(na, 1), "avg_shade_ms": mss / max(ns, 1), "seg_per_launch": S_ * 2.0 * len(seeds_a) * sample_res * W * H / max(na, 1), "launches": na,
                      "from": f"a one-stream pass after the timed region: 2 x {len(seeds_a)} frames of the same workload, the kernels alone on the chip",
                      "counters_note": "per-segment counter figures are those of the committed summary (two streams per GPU, 256-thread intersect blocks); alone on its GPU the intersect "
-                                      "kernel runs 1024-thread blocks, whose counters differ by about 1 % in VALU and 4 % in HBM bytes per segment (measured in round 3, profiles/r03_m_pmc_C3_one_stream.txt; not re-collected for later kernels)"}
+                                      "kernel runs 1024-thread blocks, whose counters were last compared in round 3 (about 1 % in VALU, 4 % in HBM bytes per segment: profiles/r03_m_pmc_C3_one_stream.txt, an older kernel generation); `vmem.alone_on_the_chip` of the top level holds the busy shares rocprofv3 measured directly with each kernel alone on the chip (a counter pass serialises the kernels)"}
             r1.close()
         out["roofline"] = roofline_block(args, src, stats, samples, shards if not args.rehearse_shard else 1, dt, value, sample_res, n_gpus=n_gpus, ext_kernel=ext_kernel, alone=alone)
         out["hbm_frac"] = out["roofline"]["hbm_frac"]      # north_star's figure at the top of the line: measured HBM bytes of both kernels / wall time / 8 TB/s

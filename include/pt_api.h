@@ -134,6 +134,12 @@ int pt_stream_wait(pt_ctx* ctx);
  * gather is then the host layer's single RCCL collective on pt_frame_device(). */
 int pt_read_frame(pt_ctx* ctx, float* rgba_out);
 
+/* glTexSubImage2D on FRAME (no call site in the reference: its accumulation dies with the window; SURVEY.md §5 "checkpoint / resume: re-upload sum + count"):
+ * writes width*height RGBA32F (layout of pt_read_frame) into the current FRAME image.  FRAME is the only state the path tracer carries from frame to frame
+ * (frag.glsl:924-933), so N frames + pt_read_frame, then — in this or a new context with the same scene — pt_write_frame + frames N+1 .. N+M equal N+M frames
+ * rendered in one go, bit for bit.  A multi-stream context distributes the image over its shards; a single shard of several takes its own pixels.  Synchronises. */
+int pt_write_frame(pt_ctx* ctx, const float* rgba_in);
+
 /* The reference's screenshot path: display colour = FRAME.rgb / frame_count (frag.glsl:932) through an
  * UNORM8 framebuffer (clamp, *255, round to nearest), glReadPixels(GL_RGB, GL_UNSIGNED_BYTE) (dispatch.java:813), the
  * signed-byte packing of :819-822 when java_bytes != 0 (a channel >= 128 borrows 1 from the channel above it), vertical flip

@@ -1180,7 +1180,9 @@ int buildScene(pt_ctx* c) {
                 if (!(A[k] <= A[3 + k])) cullable = false;                                      // ordered, no NaN
                 for (int side = 0; side < 2 && cullable; side++) {
                     const float* Ch = c->bvhdata.data() + 8 * (size_t)childOf(r, side);
-                    if (!(Ch[k] >= A[k]) || !(Ch[3 + k] <= A[3 + k])) cullable = false;          // the child box inside the root box (NaN: not)
+                    // BOTH planes of the child inside the root's range: rayBox takes min / max of the two plane distances (:412-413), so an inverted child
+                    // (min > max) whose `max` lies below the root's min would stick out of the root although its `min` and `max` each pass a one-sided test (NaN: not)
+                    if (!(Ch[k] >= A[k] && Ch[k] <= A[3 + k] && Ch[3 + k] >= A[k] && Ch[3 + k] <= A[3 + k])) cullable = false;
                 }
             }
             ObjRoot& G = groups[o >> sft];
@@ -2072,6 +2074,26 @@ int pt_read_frame(pt_ctx* c, float* out) {
     return PT_OK;
 }
 
+/* The inverse of pt_read_frame: FRAME is the path tracer's only persistent state (frag.glsl:924-933: rgb = running sum, a = count), so a saved image written
+ * back lets an interrupted accumulation go on — N frames, read, (new context,) write, M frames more = N + M frames, bit for bit. */
+int pt_write_frame(pt_ctx* c, const float* in) {
+    if (!c || !in) return fail(PT_ERR_ARG, "pt_write_frame: null argument");
+    MULTI_ALL(c, pt_write_frame(k, in));                           // every stream takes the pixels of its own tile shard
+    HIP_TRY(hipSetDevice(c->device));
+    { int rc; if ((rc = flushStream(c))) return rc; }
+    float4* const dFrame = c->dImage[c->curImage];
+    if (c->shardCount == 1) {
+        HIP_TRY(hipMemcpyAsync(dFrame, in, (size_t)c->W * c->H * 16, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return PT_OK;
+    }
+    std::vector<float> tmp((size_t)c->nSlotsImg * 4, 0.0f);       // shard-local order, the padding slots zero as pt_reset_frame leaves them
+    for (int k = 0; k < c->nLocal; k++) std::memcpy(tmp.data() + 4 * (size_t)k, in + 4 * (size_t)c->pixList[k], 16);
+    HIP_TRY(hipMemcpyAsync(dFrame, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
 int pt_read_display(pt_ctx* c, int frame_count, int java_bytes, uint8_t* rgb_out) {
     if (!c || !rgb_out) return fail(PT_ERR_ARG, "pt_read_display: null argument");
     const float4* frame = nullptr; pt_ctx* on = c;
@@ -2230,7 +2252,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 19: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "node records of the hand-written kernel: -1 automatic, 0 80-B sign-ordered, 1 64-B"); c->asmNodeLayout = (int)value; c->sceneDirty = true; return PT_OK;
         case 18: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "index-stack encoding: 0 automatic, 1 at least 8-bit codes, 2 the floats themselves"); c->forceNiBits8 = (int)value; c->sceneDirty = true; return PT_OK;
-        case 20: c->asmNoRootCull = value == 0; c->sceneDirty = true; return PT_OK;
+        case 20: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "per-ray cull of the object loop (more than 8 BVHs): 0 off, 1 on"); c->asmNoRootCull = value == 0; c->sceneDirty = true; return PT_OK;
         case 17: if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256, 512 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;
         case 13: return c->asmLaunches > (uint64_t)value ? PT_OK : fail(PT_ERR_UNSUPPORTED, "the hand-written intersect kernel has been launched " + std::to_string(c->asmLaunches) + " times");      // query (debug)

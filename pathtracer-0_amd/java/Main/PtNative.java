@@ -50,6 +50,9 @@ public final class PtNative {
     public static native void streamWait(long ctx);
     /** glReadPixels of the RGBA32F FRAME image into a direct FloatBuffer of width*height*4 floats */
     public static native void readFrame(long ctx, Buffer rgbaOut);
+    /** the inverse (pt_write_frame): a saved FRAME image — running sum + count, the path tracer's only persistent state — written back, so an
+     *  accumulation goes on where it stopped: N frames, readFrame, writeFrame, frames N+1.. = one uninterrupted run, bit for bit */
+    public static native void writeFrame(long ctx, Buffer rgbaIn);
     /** functions.screenshot's pixels (dispatch.java:804-833): width*height*3 bytes, top row first; javaBytes = keep its signed-byte packing */
     public static native void readDisplay(long ctx, int frameCount, boolean javaBytes, Buffer rgbOut);
     /** what functions.screenshot writes (dispatch.java:804-851): those pixels as an 8-bit RGB PNG at `path` (pt_save_png) */

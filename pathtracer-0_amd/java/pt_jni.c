@@ -127,3 +127,8 @@ JNIEXPORT void JNICALL Java_Main_PtNative_readFrame(JNIEnv* env, jclass c, jlong
     if (!p) return;
     CHECK(pt_read_frame(CTX(h), (float*)p), "pt_read_frame");
 }
+JNIEXPORT void JNICALL Java_Main_PtNative_writeFrame(JNIEnv* env, jclass c, jlong h, jobject in) {
+    void* p = direct(env, in, "writeFrame");
+    if (!p) return;
+    CHECK(pt_write_frame(CTX(h), (const float*)p), "pt_write_frame");
+}

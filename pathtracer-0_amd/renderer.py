@@ -96,6 +96,7 @@ def lib():
         L.pt_synchronize.argtypes = [vp]
         L.pt_stream_wait.argtypes = [vp]
         L.pt_read_frame.argtypes = [vp, vp]
+        L.pt_write_frame.argtypes = [vp, vp]
         L.pt_read_display.argtypes = [vp, ci, ci, vp]
         L.pt_save_png.argtypes = [vp, ci, ci, C.c_char_p]
         L.pt_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -240,6 +241,12 @@ class Renderer:
         assert out.dtype == np.float32 and out.flags.c_contiguous and out.size == self.W * self.H * 4
         _check(self._L.pt_read_frame(self._h, out.ctypes.data))
         return out
+
+    def write_frame(self, frame):
+        """restore a saved FRAME image (running sum + count): the next frames accumulate on top of it (pt_write_frame)"""
+        frame = np.ascontiguousarray(frame, dtype=np.float32)
+        assert frame.size == self.W * self.H * 4
+        _check(self._L.pt_write_frame(self._h, frame.ctypes.data))
 
     def read_display(self, frame_count, java_bytes=True):
         """The reference's screenshot image: (H, W, 3) uint8, top row first (functions.screenshot, dispatch.java:804-851)."""

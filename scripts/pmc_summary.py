@@ -12,6 +12,12 @@ Per kernel: counter totals over all launches of a pass, and the figures bench.py
   active_share       SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
   hbm_bytes_per_segment   (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 / segments   (gfx950: FETCH_SIZE tallies 128-B requests as 64 B,
                            /opt/skills/guides/MI355X_MICROARCH.md, HBM)
+  (round 6, the CU's vector-memory path; *_sum counters are sums over the 256 CUs' units, GRBM_GUI_ACTIVE over the 8 XCDs; rocprofv3 serialises the
+   kernels of a counter pass, so these are each kernel ALONE on the chip)
+  ta_busy_cycles_per_segment / td_busy_cycles_per_segment   TA_TA_BUSY_sum / segments, TD_TD_BUSY_sum / segments
+  ta_busy_frac_alone / td_busy_frac_alone                    the same over 256 x (GRBM_GUI_ACTIVE / 8): the share of the kernel's cycles its CU's unit is busy
+  tag_lookups_per_vmem_inst   TCP_TOTAL_CACHE_ACCESSES_sum / (SQ_INSTS_VMEM_RD + SQ_INSTS_VMEM_WR)     (a coalesced 16-B-per-lane load: 4-8)
+  l1_hit_rate                 1 - TCP_TCC_READ_REQ_sum / TCP_TOTAL_CACHE_ACCESSES_sum;   l2_round_trip_cycles   TCP_TCC_READ_REQ_LATENCY_sum / TCP_TCC_READ_REQ_sum
 segments = W * H * SAMPLE_RES * frames-per-step * 2 passes (bench.py's untimed set-up pass + 1 timed step) * S, with S = segments per
 sample from the statistics pass of the un-profiled run of the same command (plain.json; deterministic per scene and seeds).
 VALU issue roof: 256 CUs * 4 SIMDs * 2.4 GHz / 2 cycles per wave64 instruction = 1.2288e12 wave-instructions/s.
@@ -34,6 +40,7 @@ def kernel_source_hash():
 
 VALU_PEAK = 256 * 4 * 2.4e9 / 2
 HBM_PEAK = 8.0e12
+UNIT_PEAK = 256 * 2.4e9           # busy cycles per second of a per-CU unit (TA, TD) summed over the chip, at the peak engine clock
 
 
 def main(d, cfg, fps):
@@ -83,6 +90,26 @@ def main(d, cfg, fps):
                 o["hbm_fetch_bytes_per_segment_x2"] = round(2 * g("FETCH_SIZE") * 1024 / seg, 2)
                 o["hbm_write_bytes_per_segment"] = round(g("WRITE_SIZE") * 1024 / seg, 2)
                 o["hbm_bytes_per_segment"] = round((2 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024 / seg, 2)
+            if g("TA_TA_BUSY_sum"):
+                o["ta_busy_cycles_per_segment"] = round(g("TA_TA_BUSY_sum") / seg, 3)
+            if g("TD_TD_BUSY_sum"):
+                o["td_busy_cycles_per_segment"] = round(g("TD_TD_BUSY_sum") / seg, 3)
+        if g("GRBM_GUI_ACTIVE"):
+            unit_cycles = 256.0 * g("GRBM_GUI_ACTIVE") / 8.0
+            if g("TA_TA_BUSY_sum"):
+                o["ta_busy_frac_alone"] = round(g("TA_TA_BUSY_sum") / unit_cycles, 4)
+            if g("TD_TD_BUSY_sum"):
+                o["td_busy_frac_alone"] = round(g("TD_TD_BUSY_sum") / unit_cycles, 4)
+                o["td_waiting_for_cache_frac_alone"] = round(g("TD_TC_STALL_sum", 0) / unit_cycles, 4)
+            if g("TA_ADDR_STALLED_BY_TC_CYCLES_sum") is not None:
+                o["ta_addr_stalled_by_cache_frac_alone"] = round(g("TA_ADDR_STALLED_BY_TC_CYCLES_sum", 0) / unit_cycles, 4)
+        if g("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            vm = g("SQ_INSTS_VMEM_RD", 0) + g("SQ_INSTS_VMEM_WR", 0)
+            if vm:
+                o["tag_lookups_per_vmem_inst"] = round(g("TCP_TOTAL_CACHE_ACCESSES_sum") / vm, 2)
+            o["l1_hit_rate"] = round(1.0 - g("TCP_TCC_READ_REQ_sum", 0) / g("TCP_TOTAL_CACHE_ACCESSES_sum"), 4)
+            if g("TCP_TCC_READ_REQ_sum"):
+                o["l2_round_trip_cycles"] = round(g("TCP_TCC_READ_REQ_LATENCY_sum", 0) / g("TCP_TCC_READ_REQ_sum"), 1)
         if g("SQ_ACTIVE_INST_VALU"):
             o["lane_util"] = round(g("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4)
         if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
@@ -105,6 +132,9 @@ def main(d, cfg, fps):
             seg_rate = (seg / 2.0) / (pr["extend_avg_launch_ms"] * 1e-3 * pr["extend_launches"])      # segments/s while the kernel runs (timed step of the plain run)
             o["segments_per_s_in_kernel"] = seg_rate
             o["valu_issue_frac"] = round(o["valu_per_segment"] * seg_rate / VALU_PEAK, 4)
+            for u in ("ta", "td"):                   # the unit's busy cycles over 256 units x 2.4 GHz while the kernel runs beside the other stream (the plain run's launch durations)
+                if f"{u}_busy_cycles_per_segment" in o:
+                    o[f"{u}_busy_frac_in_run"] = round(o[f"{u}_busy_cycles_per_segment"] * seg_rate / UNIT_PEAK, 4)
             if "hbm_bytes_per_segment" in o:
                 o["hbm_frac"] = round(o["hbm_bytes_per_segment"] * seg_rate / HBM_PEAK, 4)
     json.dump(out, open(f"{d}/summary.json", "w"), indent=1)

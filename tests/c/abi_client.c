@@ -30,6 +30,7 @@ static int (*pt_set_texture_)(pt_ctx*, int, int, int, const uint8_t*);
 static int (*pt_reset_frame_)(pt_ctx*);
 static int (*pt_render_)(pt_ctx*, int, int);
 static int (*pt_read_frame_)(pt_ctx*, float*);
+static int (*pt_write_frame_)(pt_ctx*, const float*);
 /* the rest of the boundary (every non-debug symbol of pt_api.h is driven below) */
 static int (*pt_create_multi_)(pt_ctx**, const int*, int, int, int);
 static int (*pt_create_multi_part_)(pt_ctx**, const int*, int, int, int, int, int);
@@ -88,7 +89,7 @@ int main(int argc, char** argv) {
     SYM(host, pts_create) SYM(host, pts_destroy) SYM(host, pts_last_error) SYM(host, pts_add_material) SYM(host, pts_set_last_mtl)
     SYM(host, pts_add_object_text) SYM(host, pts_add_ellipsoid) SYM(host, pts_pack) SYM(host, pts_get_buffer)
     SYM(hip, pt_create) SYM(hip, pt_destroy) SYM(hip, pt_last_error) SYM(hip, pt_set_buffer) SYM(hip, pt_set_texture) SYM(hip, pt_reset_frame)
-    SYM(hip, pt_render) SYM(hip, pt_read_frame)
+    SYM(hip, pt_render) SYM(hip, pt_read_frame) SYM(hip, pt_write_frame)
     SYM(hip, pt_create_multi) SYM(hip, pt_create_multi_part) SYM(hip, pt_stream_wait) SYM(hip, pt_render_batch) SYM(hip, pt_render_batch_async) SYM(hip, pt_next_image) SYM(hip, pt_finish_image) SYM(hip, pt_image_device)
     SYM(hip, pt_gather_image) SYM(hip, pt_synchronize) SYM(hip, pt_read_display) SYM(hip, pt_save_png) SYM(hip, pt_frame_device) SYM(hip, pt_shard_slots) SYM(hip, pt_shard_map)
     SYM(hip, pt_unshard) SYM(hip, pt_set_stream) SYM(hip, pt_build_bvh) SYM(hip, pt_get_counters) SYM(hip, pt_reset_counters)
@@ -131,6 +132,13 @@ int main(int argc, char** argv) {
     /* pt_render_batch == the same pt_render calls */
     REQUIRE(pt_reset_frame_(ctx) == 0 && pt_render_batch_(ctx, 1, frames, seeds) == 0 && pt_synchronize_(ctx) == 0 && pt_read_frame_(ctx, other) == 0, "pt_render_batch");
     REQUIRE(memcmp(frame, other, fbytes) == 0, "pt_render_batch == frame-at-a-time");
+    /* pt_write_frame: the first frame's image written back, the remaining frames on top == all frames in one go */
+    if (frames >= 2) {
+        REQUIRE(pt_reset_frame_(ctx) == 0 && pt_render_(ctx, 1, seeds[0]) == 0 && pt_read_frame_(ctx, other) == 0, "first frame alone");
+        REQUIRE(pt_reset_frame_(ctx) == 0 && pt_write_frame_(ctx, other) == 0 && pt_render_batch_(ctx, 2, frames - 1, seeds + 1) == 0 && pt_read_frame_(ctx, other) == 0, "pt_write_frame");
+        REQUIRE(memcmp(frame, other, fbytes) == 0, "pt_write_frame + the remaining frames == all frames");
+        REQUIRE(pt_write_frame_(ctx, NULL) == PT_ERR_ARG, "pt_write_frame(NULL) is refused");
+    }
     /* overlapped form: new image, asynchronous batches, finish, read */
     void* dptr = NULL; size_t nslots = 0;
     REQUIRE(pt_next_image_(ctx) == 0 && pt_render_batch_async_(ctx, 1, 1, seeds) == 0 && (frames < 2 || pt_render_batch_async_(ctx, 2, frames - 1, seeds + 1) == 0) &&

@@ -60,6 +60,7 @@ jlong Java_Main_PtNative_gatherImage(JNIEnv*, jclass, jlong, jint);
 void Java_Main_PtNative_synchronize(JNIEnv*, jclass, jlong);
 void Java_Main_PtNative_streamWait(JNIEnv*, jclass, jlong);
 void Java_Main_PtNative_readFrame(JNIEnv*, jclass, jlong, jobject);
+void Java_Main_PtNative_writeFrame(JNIEnv*, jclass, jlong, jobject);
 void Java_Main_PtNative_readDisplay(JNIEnv*, jclass, jlong, jint, jboolean, jobject);
 void Java_Main_PtNative_savePng(JNIEnv*, jclass, jlong, jint, jboolean, jstring);
 jlongArray Java_Main_PtNative_getCounters(JNIEnv*, jclass, jlong);
@@ -128,6 +129,13 @@ int main(int argc, char** argv) {
     if (!two) { jlong n[1] = {0}; struct _jlongArray slots = {1, n}; jlong p = Java_Main_PtNative_imageDevice(env, cls, ctx, 1, &slots); NO_EXCEPTION("imageDevice");
                 if (!p || n[0] < (jlong)W * H) { fprintf(stderr, "imageDevice: %lld slots\n", (long long)n[0]); return 1; } }
     else { Java_Main_PtNative_imageDevice(env, cls, ctx, 1, NULL); EXPECT_EXCEPTION("java/lang/RuntimeException", "imageDevice on a several-stream context"); }
+    /* resume: the image of frames 1..6 written back into a fresh image, frame 7 on top of it */
+    Java_Main_PtNative_nextImage(env, cls, ctx); NO_EXCEPTION("nextImage");
+    { struct _jobject in = {frame, (jlong)nf}; Java_Main_PtNative_writeFrame(env, cls, ctx, &in); NO_EXCEPTION("writeFrame"); }
+    Java_Main_PtNative_render(env, cls, ctx, 7, 6667); NO_EXCEPTION("render (frame 7 after writeFrame)");
+    { struct _jobject out = {frame, (jlong)nf}; Java_Main_PtNative_readFrame(env, cls, ctx, &out); NO_EXCEPTION("readFrame"); }
+    { char p[1024]; snprintf(p, sizeof p, "%s/frame7.bin", dir); FILE* f = fopen(p, "wb"); fwrite(frame, sizeof(float), nf, f); fclose(f); }
+    { struct _jobject heap = {NULL, 0}; Java_Main_PtNative_writeFrame(env, cls, ctx, &heap); EXPECT_EXCEPTION("java/lang/IllegalArgumentException", "writeFrame(heap buffer)"); }
     Java_Main_PtNative_destroy(env, cls, ctx); NO_EXCEPTION("destroy");
     if (array_elements_out) { fprintf(stderr, "%d Get...Elements / GetStringUTFChars without their Release\n", array_elements_out); return 1; }
     printf("JNI_HARNESS_OK\n");

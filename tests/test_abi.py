@@ -146,7 +146,7 @@ def test_jni_shim_covers_the_boundary():
     called = set(re.findall(r"\b(pt_[a-z_]+)\(", jni))
     assert called <= api, called - api
     for need in ("pt_create", "pt_create_multi", "pt_create_multi_part", "pt_stream_wait", "pt_destroy", "pt_set_buffer", "pt_set_texture", "pt_reset_frame", "pt_render", "pt_render_batch", "pt_render_batch_async",
-                 "pt_next_image", "pt_finish_image", "pt_image_device", "pt_gather_image", "pt_synchronize", "pt_read_frame", "pt_read_display", "pt_get_counters",
+                 "pt_next_image", "pt_finish_image", "pt_image_device", "pt_gather_image", "pt_synchronize", "pt_read_frame", "pt_write_frame", "pt_read_display", "pt_get_counters",
                  "pt_reset_counters", "pt_last_error"):
         assert need in called, need
 
@@ -229,7 +229,10 @@ def test_jni_shim_runs_without_a_jvm(pt, renderer_mod, tmp_path, two_streams):
     r = renderer_mod.Renderer(W, H)
     r.load_workload(wl); r.reset_frame(); r.reset_counters()
     r.render_batch(1, seeds)
-    ref = r.read_frame().copy(); disp = r.read_display(6, java_bytes=True); cnt = r.counters(); r.close()
+    ref = r.read_frame().copy(); disp = r.read_display(6, java_bytes=True); cnt = r.counters()
+    r.render(7, 6667); ref7 = r.read_frame().copy(); r.close()
+    got7 = np.fromfile(str(d / "frame7.bin"), dtype=np.float32).reshape(H, W, 4)
+    assert np.array_equal(got7, ref7, equal_nan=True) and np.all(got7[..., 3] == 7)      # writeFrame(frames 1..6) + frame 7 == seven frames in one go
     got = np.fromfile(str(d / "frame.bin"), dtype=np.float32).reshape(H, W, 4)
     assert np.array_equal(got, ref, equal_nan=True) and np.all(got[..., 3] == 6)
     assert np.array_equal(np.fromfile(str(d / "display.bin"), dtype=np.uint8).reshape(disp.shape), disp)

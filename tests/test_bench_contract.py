@@ -20,7 +20,37 @@ def test_committed_bench_line_has_the_contract_keys():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    if os.path.basename(latest) >= "r05":
+    if os.path.basename(latest) >= "r06":
+        # round 6: the top level is the resource DESIGN.md 7.1 finds binding — the CU's vector-memory path for divergent fetches — as the busy share of its data-return
+        # unit in the timed configuration (TD_TD_BUSY_sum per segment from the committed counter summary of THIS tree's kernels x the live segment rate / 256 units x 2.4 GHz);
+        # VALU issue is the sub-block `valu_issue`; `hbm_frac`, `hbm`, `alone`, `shade`, `algorithmic` as in round 5
+        assert r["bound"] == "vmem_divergent" and 0 < r["frac"] <= 1 and r["counters_stale"] is False and r["peak"] == 614.4
+        prof = json.load(open(os.path.join(ROOT, r["counters_from"])))
+        pk = prof["kernels"][r["kernel"]]
+        vm = r["vmem"]
+        assert abs(pk["td_busy_cycles_per_segment"] - vm["td_busy"]["cycles_per_segment"]) < 1e-9 and vm["provisional"] is False
+        assert abs(r["achieved"] - vm["td_busy"]["cycles_per_segment"] * r["segments_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 2e-2
+        assert r["frac"] == vm["td_busy"]["frac"] and 0 < vm["ta_busy"]["frac"] <= 1 and 0 < vm["alone_on_the_chip"]["td_busy_frac_alone"] <= 1 and 0 < vm["alone_on_the_chip"]["ta_busy_frac_alone"] <= 1
+        assert vm["tag_lookups_per_vmem_inst"] > 1 and 0 < vm["l1_hit_rate"] < 1
+        v = r["valu_issue"]
+        assert abs(pk["valu_per_segment"] - v["valu_insts_per_segment"]) < 1e-9 and 0 < v["lane_util"] <= 1 and 0 < v["frac"] <= 1 and v["unit"] == "Ginst/s"
+        assert abs(v["achieved"] - v["valu_insts_per_segment"] * r["segments_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / v["achieved"] < 2e-2
+        assert abs(r["traffic"] - pk["hbm_bytes_per_segment"] * r["segments_per_launch"]) / r["traffic"] < 1e-2
+        h = r["hbm"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in h, k
+        assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and 0 < h["frac"] <= 1 and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-3
+        assert r["hbm_frac"] == h["frac"] == d["hbm_frac"]
+        assert 0 < h[r["kernel"]]["frac"] <= 1 and 0 < h["k_shade"]["frac"] <= 1 and 0 < r["chip_valu_issue"]["frac"] <= 1
+        assert "measured_in" in r["alone"] and 0 < r["alone"]["valu_issue"]["frac"] <= 1 and 0 < r["alone"]["hbm"]["frac"] <= 1 and 0 < r["alone"]["td_busy"]["frac"] <= 1
+        assert r["shade"]["bound"] == "hbm" and 0 < r["shade"]["frac"] <= 1
+
+        def no_frac_key(o):
+            return all(k != "frac" and no_frac_key(v) for k, v in o.items()) if isinstance(o, dict) else True
+        assert no_frac_key(r["algorithmic"]) and r["algorithmic"]["extend_GBps"] > 0
+        assert d["hip_runtime"]["version"] and d["hip_runtime"]["runtimes_mapped"] == 1
+        assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["cores_available"] and d["readback"]["ms_per_image"] > 0
+    elif os.path.basename(latest) >= "r05":
         # round 5: every fraction of the line is a fraction of a roof the hardware can reach.  Top level = the dominant kernel against the resource that binds it
         # (vector-instruction issue), `hbm_frac` (in the block and at the top of the line) = measured HBM bytes of both kernels over the wall time / 8 TB/s,
         # `hbm` = the same in the contract's bound / achieved / peak / unit / frac / traffic form; SURVEY.md 8(d)'s algorithmic bytes sit under `algorithmic` without a fraction

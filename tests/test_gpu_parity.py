@@ -317,11 +317,14 @@ def test_implicit_surfaces_are_accepted_and_never_hit(pt, oracle, renderer_mod):
     assert np.array_equal(got, plain, equal_nan=True) and np.array_equal(ref, ref0, equal_nan=True)
 
 
-@pytest.mark.parametrize("perturb", ["children_stick_out", "root_box_shrunk_to_nothing", "inverted_root_box"])
+@pytest.mark.parametrize("perturb", ["children_stick_out", "root_box_shrunk_to_nothing", "inverted_root_box", "inverted_child_box"])
 def test_root_cull_only_where_the_boxes_promise_it(pt, renderer_mod, perturb):
     """The per-ray cull of the object loop skips a BVH whose ROOT box the ray misses; that is rayBVH's own result only if the root's child boxes lie inside an
     ordered root box (the reference's builder guarantees it, the C ABI takes any buffer).  Root boxes made smaller than their children, shrunk to a point far
-    away, or inverted: the hand-written kernel must still equal the compiled kernels (which test every root box in turn) bit for bit."""
+    away, or inverted: the hand-written kernel must still equal the compiled kernels (which test every root box in turn) bit for bit.
+    inverted_child_box (round-5 advisor): the root box covers only the lower half of its triangles and both children are stored (max, min) — each plane of a child
+    passes a one-sided test against the root (min >= root.min, max <= root.max) while the slab rayBox makes of it, [max, min], sticks out of the root; a ray with
+    closest_t still 1e30 that misses the root is traversed by the reference (1e30 > 1e30 is false) and meets the triangles of the upper half."""
     W, H = 64, 36
     wl = pt.scenes.build("C6", W, H, groups=24, nu=6, nv=6)
     b = dict(wl.buffers)
@@ -333,14 +336,25 @@ def test_root_cull_only_where_the_boxes_promise_it(pt, renderer_mod, perturb):
             mid = 0.5 * (lo + hi); data[r, 0:3] = mid - 0.25 * (hi - lo); data[r, 3:6] = mid + 0.25 * (hi - lo)
         elif perturb == "root_box_shrunk_to_nothing":
             data[r, 0:3] = 50.0 + k; data[r, 3:6] = 50.0 + k
+        elif perturb == "inverted_child_box":
+            tree = np.asarray(b[11]).reshape(-1, 3)
+            data[r, 4] = 0.5 * (lo[1] + hi[1])                # the root: lower half in y
+            for ch in (int(tree[r, 1]), int(tree[r, 2])):
+                cl, chh = data[ch, 0:3].copy(), data[ch, 3:6].copy()
+                data[ch, 0:3] = chh; data[ch, 3:6] = cl
         else:
             data[r, 0:3] = hi; data[r, 3:6] = lo
     b[10] = data.reshape(-1)
     wl = pt.scenes.Workload("C6p", W, H, b, wl.sky, wl.sample_res, wl.max_bounces, wl.info)
     o, d = mixed_regular_and_axis_parallel_rays(wl, 1 << 16, 12)
+    if perturb == "inverted_child_box":                       # a quarter of the rays start inside the room and leave through its open side: no wall behind the tori, closest_t stays 1e30
+        rs = np.random.RandomState(5); n4 = o.shape[0] // 4
+        o[:n4] = rs.uniform((-0.9, 0.1, -0.9), (0.9, 1.9, 0.9), size=(n4, 3)).astype(np.float32)
+        dd = rs.normal(size=(n4, 3)); dd[:, 2] = -np.abs(dd[:, 2]) - 0.5
+        d[:n4] = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
     r = renderer_mod.Renderer(W, H)
     r.load_workload(wl)
-    if perturb == "inverted_root_box":
+    if perturb in ("inverted_root_box", "inverted_child_box"):
         r.set_option("asm_node_layout", 1)                    # (an inverted box is what the 80-B sign-ordered records cannot hold: such scenes run the compiled kernel; the 64-B layout's min/max step takes them)
     assert asm_taken(r)
     out = {}
@@ -381,6 +395,30 @@ def test_render_parity_handwritten_kernel(pt, oracle, renderer_mod, name, W, H, 
     r.close()
     ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, frames, seeds, nthreads=8)
     assert_same(got, ref)
+
+
+@pytest.mark.parametrize("groups", [64, 65])
+@pytest.mark.parametrize("tpb", [256, 1024])
+def test_group_cull_boundaries_at_full_size(pt, oracle, renderer_mod, groups, tpb):
+    """The one abort this repository ever saw on a committed-next kernel (gpurun r05b, DESIGN.md section 2.2: the first FULL-SIZE many-BVH render, C6 at 1920x1080 on the
+    1024-thread blocks a context alone on its GPU takes) was found by no small case: the per-ray group cull at its boundaries — 64 groups (one BVH per mask bit, every
+    bit used) and 65 (two BVHs per bit, 33 bits) — on both block sizes AT 1920x1080, where a launch has its 512 large blocks, the LDS allocation is the production
+    one (32 KB tile + root records + group boxes + 16 stack levels x 1024 lanes) and 16 M rays per frame reach the deep ends of the traversal stacks.
+    One frame each, against the oracle on a pixel lattice."""
+    W, H = 1920, 1080
+    wl = pt.scenes.build("C6", W, H, groups=groups, nu=10, nv=10)
+    seeds = seeds_for(pt, 1, 1)
+    r = renderer_mod.Renderer(W, H)
+    r.set_option("asm_tpb", tpb)
+    r.load_workload(wl); r.reset_frame()
+    r.render_batch(1, seeds)
+    got = r.read_frame().copy()
+    assert asm_taken(r)
+    r.close()
+    ref = np.zeros((H, W, 4), np.float32)
+    oracle.render(oracle.Scene.from_workload(wl), W, H, 1, seeds[0], ref, nthreads=8, xs=32, ys=27)
+    assert np.array_equal(got[::27, ::32].view(np.uint32), ref[::27, ::32].view(np.uint32)) or np.array_equal(got[::27, ::32], ref[::27, ::32], equal_nan=True)
+    assert np.all(got[..., 3] == 1.0)
 
 
 @pytest.mark.parametrize("name,frames,xs,ys,streams,bound", [("C1", 1, 1, 1, 1, 1e-3), ("C2", 8, 8, 9, 1, 6e-3), ("C2", 512, 16, 18, 2, 1e-3), ("C3", 32, 24, 27, 2, 1e-3),
@@ -504,6 +542,45 @@ def test_batch_equals_frame_at_a_time_and_frame_counter(pt, oracle, renderer_mod
     r.close()
     assert np.array_equal(a, b)
     assert np.all(a[..., 3] == 4.0) and np.all(c[..., 3] == 1.0)
+
+
+@pytest.mark.parametrize("form", ["one", "two_streams", "shards", "async"])
+def test_write_frame_resumes_an_accumulation(pt, oracle, renderer_mod, form):
+    """FRAME (running sum + count, frag.glsl:924-933) is the path tracer's only persistent state (resumability = re-upload sum + count):
+    N frames, pt_read_frame, the context destroyed, a new one, pt_write_frame, M more frames == N + M frames in one go, bit for bit and against the oracle —
+    on one stream, on a two-stream context (the image is distributed over the tile shards), on single shards of three, and with the resumed frames submitted
+    asynchronously into a fresh image of the ring."""
+    W, H, N, M = 96, 54, 3, 2
+    wl = pt.scenes.build("C3", W, H)
+    seeds = seeds_for(pt, 1, N + M)
+    make = (lambda: renderer_mod.Renderer(W, H, devices=[0, 0])) if form == "two_streams" else (lambda: renderer_mod.Renderer(W, H))
+    r = make(); r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds)
+    whole = r.read_frame().copy(); r.close()
+    r = make(); r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds[:N])
+    saved = r.read_frame().copy(); r.close()
+    assert np.all(saved[..., 3] == N)
+    if form == "shards":
+        acc = np.zeros_like(whole)
+        for rank in range(3):
+            rr = renderer_mod.Renderer(W, H, shard_rank=rank, shard_count=3)
+            rr.load_workload(wl); rr.reset_frame(); rr.write_frame(saved); rr.render_batch(N + 1, seeds[N:])
+            part = rr.read_frame(); rr.close()
+            assert np.all(acc[part[..., 3] > 0] == 0)
+            acc += part
+        got = acc
+    else:
+        r = make(); r.load_workload(wl)
+        if form == "async":
+            r.reset_frame(); r.render_batch_async(1, seeds[:1]); r.next_image()      # something else in flight in the previous image of the ring
+            r.write_frame(saved)
+            for k in range(M):
+                r.render_batch_async(N + 1 + k, seeds[N + k:N + k + 1])
+        else:
+            r.reset_frame(); r.write_frame(saved); r.render_batch(N + 1, seeds[N:])
+        got = r.read_frame().copy(); r.close()
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)) and np.all(got[..., 3] == N + M)
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, N + M, seeds, nthreads=8)
+    assert_same(got, ref)
 
 
 def test_sharding_invariance(pt, oracle, renderer_mod):
