@@ -241,7 +241,7 @@ def test_bench_default_is_two_streams_on_one_gpu():
     r = d["roofline"]
     assert r["bound"] == "vmem_divergent" and r["streams_per_gpu"] == 2 and 0 < r["chip_valu_issue"]["frac"] <= 1 and 0 < r["hbm"]["frac"] <= 1 and 0 < r["valu_issue"]["frac"] <= 1
     if r["counters_stale"]:      # the committed counter summary belongs to other kernel sources (a tree between two measurement passes): the headline fractions are withheld
-        assert r["frac"] is None and r["hbm_frac"] is None and d["hbm_frac"] is None and r["note"].startswith("COUNTERS STALE") and r["valu_issue"]["provisional"] is True
+        assert r["frac"] is None and r["hbm_frac"] is None and d["hbm_frac"] is None and "COUNTERS STALE" in r["note"] and r["valu_issue"]["provisional"] is True
     else:
         assert 0 < r["frac"] <= 1 and r["frac"] == r["vmem"]["td_busy"]["frac"] and r["hbm_frac"] == r["hbm"]["frac"] == d["hbm_frac"]
     assert "measured_in" in r["alone"] and d["readback"]["ms_per_image"] > 0 and d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["cores_available"]
