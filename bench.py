@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="gloo: the process-per-GPU form with the collective on CPU tensors — "
                     "rehearses every line of the N > 1 path where the ranks cannot have a GPU each (with PT_BENCH_ONE_GPU=1 all ranks use GPU 0)")
     ap.add_argument("--dist", action="store_true", help="take the torch.distributed path even at WORLD_SIZE 1 (exercises the RCCL gather of the process-per-GPU form on one GPU)")
-    for name in ("lds-budget", "extend-mode", "extend-tpb", "extend-cache", "refill-min", "none-min", "extend-blocks-per-cu", "inner-keep", "bfs-nodes", "stack-mode", "asm-loop", "asm-tpb", "asm-node-layout", "asm-root-cull"):
+    for name in ("lds-budget", "extend-mode", "extend-tpb", "extend-cache", "refill-min", "none-min", "extend-blocks-per-cu", "inner-keep", "bfs-nodes", "stack-mode", "asm-loop", "asm-tpb", "asm-node-layout", "asm-root-cull", "cu-partition"):
         ap.add_argument("--" + name, type=int, default=None)
     ap.add_argument("--rehearse-shard", type=int, nargs=2, metavar=("RANK", "COUNT"), default=None,
                     help="single-process rehearsal of ONE tile shard of a COUNT-GPU run (no collective); reports that shard's rate")
@@ -318,7 +318,7 @@ def main():
         r.set_option("path_slots", args.path_slots)
     for name, val in (("lds_budget", args.lds_budget), ("extend_mode", args.extend_mode), ("extend_tpb", args.extend_tpb), ("extend_cache_bytes", args.extend_cache),
                       ("refill_min", args.refill_min), ("none_min", args.none_min), ("extend_blocks_per_cu", args.extend_blocks_per_cu), ("inner_keep_eighths", args.inner_keep), ("bfs_nodes", args.bfs_nodes), ("stack_mode", args.stack_mode),
-                      ("asm_loop", args.asm_loop), ("asm_tpb", args.asm_tpb), ("asm_node_layout", args.asm_node_layout), ("asm_root_cull", args.asm_root_cull)):
+                      ("asm_loop", args.asm_loop), ("asm_tpb", args.asm_tpb), ("asm_node_layout", args.asm_node_layout), ("asm_root_cull", args.asm_root_cull), ("cu_partition", args.cu_partition)):
         if val is not None:
             r.set_option(name, val)
     if args.contract == "fast":
@@ -491,7 +491,7 @@ def main():
             # the kernels ALONE on the chip: two steps of the same workload on a one-stream context, after the timed region
             r1 = renderer.Renderer(W, H, device=devices[0])
             for name, val in (("extend_mode", args.extend_mode), ("extend_cache_bytes", args.extend_cache), ("refill_min", args.refill_min), ("none_min", args.none_min),
-                              ("asm_loop", args.asm_loop), ("asm_tpb", args.asm_tpb), ("asm_node_layout", args.asm_node_layout), ("asm_root_cull", args.asm_root_cull), ("path_slots", args.path_slots), ("numeric_contract", 1 if args.contract == "fast" else None)):
+                              ("asm_loop", args.asm_loop), ("asm_tpb", args.asm_tpb), ("asm_node_layout", args.asm_node_layout), ("asm_root_cull", args.asm_root_cull), ("cu_partition", args.cu_partition), ("path_slots", args.path_slots), ("numeric_contract", 1 if args.contract == "fast" else None)):
                 if val is not None:
                     r1.set_option(name, val)
             r1.load_workload(wl); r1.reset_frame()

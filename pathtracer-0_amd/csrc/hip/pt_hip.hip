@@ -875,6 +875,9 @@ struct pt_ctx {
     MultiCtx* multi = nullptr;      // != nullptr: a multi-GPU group (pt_create_multi, pt_multi.hpp); everything below then lives in its per-device contexts
     int device = 0, W = 0, H = 0, shardRank = 0, shardCount = 1;
     hipStream_t ownStream = nullptr, stream = nullptr;
+    // spatial partition (pt_set_option 21, an experiment: profiles/r06_c_cu_partition.txt): the intersect launches on a stream whose CU mask holds cuPartition eighths of
+    // every XCD's CUs, the shading launches on the complement; events order extend(i) -> shade(i) -> extend(i+1), everything else stays on `stream`
+    int cuPartition = 0, cuPartitionBuilt = 0; hipStream_t sExt = nullptr, sShade = nullptr; hipEvent_t evExt = nullptr, evShade = nullptr, evHost = nullptr;
     // raw SSBO contents (host copies, glBufferData semantics)
     std::vector<float> origin, rotation, mouse, tris, params, imp, ellip, bvhdata, mtl;
     std::vector<int32_t> bvhtree, leaftris, objidx;
@@ -1381,13 +1384,15 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // Alone on its GPU the kernel therefore runs 2 blocks of 1024 threads per CU over a 32 KB tile instead of 8 x 256 over 8 KB (C3 +6.6 %, C4 +10 %,
     // C5 +7 %, C2 +-0).  When the context's streams share the GPU the small blocks win (their slots free one by one for the other stream's
     // shading blocks: 1024-thread blocks -4...7 %), and so they do for a launch too small to give every CU its two large blocks.
-    const bool sharedGpu = c->streamsOnDevice > 1;
+    const bool part = c->sExt != nullptr && pr.stream == c->sExt;      // spatial partition: the kernel has its CUs to itself, but only those
+    const int cus = part ? c->numCUs * c->cuPartitionBuilt / 8 : c->numCUs;
+    const bool sharedGpu = c->streamsOnDevice > 1 && !part;
     const bool lazyRoots = sc.numObj > 8;                      // more than 8 BVHs: root records in LDS, tested when a BVH's turn comes (no per-lane distances)
     const size_t entryBytes = c->stackMode == 2 ? 3 : 2;       // traversal-stack entry in LDS: 16 bits (+ 2 in registers: Packed18), or 16 + 8 (24-bit entries)
     const size_t perLane = (lazyRoots ? 0 : (size_t)sc.numObj * 4) + (size_t)c->stackDepth * entryBytes;      // root-box distances + traversal stack of one lane
     const size_t rootBytes = lazyRoots ? ((size_t)sc.numObj + 64) * 32 : 0;      // the root records and the 64 group boxes of the per-ray cull (buildScene)
     const bool largeFits = 2 * (perLane * 1024 + rootBytes + 48 + 16384) <= (size_t)160 * 1024;      // two large blocks per CU with at least a 16 KB tile each (deep trees: stacks)
-    const int TPB = c->asmTpb ? c->asmTpb : (!sharedGpu && largeFits && pr.launched >= (uint64_t)c->numCUs * 2048 ? 1024 : 256);
+    const int TPB = c->asmTpb ? c->asmTpb : (!sharedGpu && c->streamsOnDevice == 1 && largeFits && pr.launched >= (uint64_t)cus * 2048 ? 1024 : 256);
     const int BPW = TPB / 256;                                  // how many 256-thread blocks one block stands for
     const size_t fixed = (lazyRoots ? rootBytes : (size_t)sc.numObj * 4 * TPB) + 48 + (size_t)c->stackDepth * entryBytes * TPB;      // root-box distances (or root records), root references + ray cursor, traversal stacks
     const size_t ldsPerCU = 160 * 1024;                        // gfx950; one block may take all of it
@@ -1397,7 +1402,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     // leaves let the other stream's shading blocks run beside it instead of behind it (C3 +3.5 %, C4 +3 %, C5 +2.5 % over 8 blocks,
     // profiles/r03_d_blocks_per_cu_and_tile.txt) — unless the whole scene fits the small tile anyway (C2).
     const bool wholeSceneInSmallTile = (size_t)sc.nNodes * (size_t)c->asmNodeStride + (size_t)sc.nTriRecs * 48 <= 8192;
-    const bool shareSlots = c->streamsOnDevice > 1 && !wholeSceneInSmallTile;
+    const bool shareSlots = sharedGpu && !wholeSceneInSmallTile;
     const int maxBlocks = std::max(1, (c->extendMaxBlocksPerCU > 0 ? std::min(c->extendMaxBlocksPerCU, 8) : (shareSlots ? 6 : 8)) / BPW);
     const size_t tileWanted = c->extendCacheSet ? (size_t)c->extendCacheBytes : (shareSlots ? 16384 : 8192) * (size_t)BPW;
     size_t cb = std::min<size_t>(tileWanted, ldsPerCU - fixed);
@@ -1413,7 +1418,7 @@ bool launchExtendAsm(pt_ctx* c, const PoolRun& pr) {
     size_t lds = (size_t)a.ldsNodes * NS + (size_t)a.ldsTris * 48 + fixed;
     lds = (lds + 15) & ~(size_t)15;
     int perCU = std::max(1, std::min((int)(ldsPerCU / lds), maxBlocks));
-    int grid = c->numCUs * perCU;
+    int grid = cus * perCU;
     grid = std::max(1, std::min(grid, ((int)pr.launched + TPB - 1) / TPB));
     const bool fastRcp = c->streamFast && !c->debugExactExtend;
     const int variant = (c->stackMode == 2 ? (fastRcp ? 5 : 4) : (c->stackMode == 1 ? 1 : 0) + (fastRcp ? 2 : 0)) + (TPB == 1024 ? 6 : TPB == 512 ? 12 : 0);
@@ -1518,6 +1523,29 @@ int retireFront(pt_ctx* c) {
     return 0;
 }
 
+// CU-masked streams of the spatial partition.  Bit k of a mask is CU k in the driver's order; whether consecutive bits walk the CUs of one XCD or the XCDs round-robin,
+// the pattern ((k / 8) + (k % 8)) % 8 < e puts 4 e of every XCD's 32 CUs on the intersect side.
+int ensurePartition(pt_ctx* c) {
+    if (c->cuPartition == c->cuPartitionBuilt) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->sExt) { hipStreamSynchronize(c->sExt); hipStreamDestroy(c->sExt); c->sExt = nullptr; }
+    if (c->sShade) { hipStreamSynchronize(c->sShade); hipStreamDestroy(c->sShade); c->sShade = nullptr; }
+    c->cuPartitionBuilt = 0;
+    if (c->cuPartition > 0) {
+        const int words = (c->numCUs + 31) / 32;
+        std::vector<uint32_t> mE((size_t)words, 0u), mS((size_t)words, 0u);
+        for (int k = 0; k < c->numCUs; k++) {
+            const bool ext = ((k / 8) + (k % 8)) % 8 < c->cuPartition;
+            (ext ? mE : mS)[(size_t)k / 32] |= 1u << (k % 32);
+        }
+        HIP_TRY(hipExtStreamCreateWithCUMask(&c->sExt, (uint32_t)words, mE.data()));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&c->sShade, (uint32_t)words, mS.data()));
+        if (!c->evExt) { HIP_TRY(hipEventCreateWithFlags(&c->evExt, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evShade, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evHost, hipEventDisableTiming)); }
+        c->cuPartitionBuilt = c->cuPartition;
+    }
+    return 0;
+}
+
 enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // PUMP_IDLE: every batch retired.  PUMP_ISSUED: the jobs not yet handed out fit into roughly one more group of iterations
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
@@ -1525,6 +1553,9 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 int pump(pt_ctx* c, PumpUntil until, int arg) {
     if (c->pending.empty()) return 0;
     hipStream_t s = c->stream;
+    { int rc = ensurePartition(c); if (rc) return rc; }
+    const bool part = c->sExt != nullptr && s == c->ownStream;
+    hipStream_t sx = part ? c->sExt : s, ss = part ? c->sShade : s;
     // the Parameters block the running stream was started with: a later pt_set_buffer(PT_BIND_PARAMS) only takes effect with the
     // next stream (submitBatch finishes this one first), so the remaining iterations keep their kernel variants and bounds
     const float* P = c->streamIn.params;
@@ -1563,20 +1594,22 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             else if (kick) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, (int64_t)c->lastSubmitJobs / perIter));
         }
         kick = false;
+        if (part) { HIP_TRY(hipEventRecord(c->evHost, s)); HIP_TRY(hipStreamWaitEvent(sx, c->evHost, 0)); }      // what `s` holds (submission, revive, accumulate) comes first
         for (int k = 0; k < CHECK; k++) {
-            PoolRun pr; pr.stream = s; pr.st = c->st; pr.launched = c->launched; pr.iter = c->iter;
+            PoolRun pr; pr.stream = sx; pr.st = c->st; pr.launched = c->launched; pr.iter = c->iter;
             const int grid = std::max(1, (int)((pr.launched + BLOCK - 1) / BLOCK));
             if (c->extendMode == 0) {
-                if (c->countStats) TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
-                else TIMED_LAUNCH(0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, s, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
+                if (c->countStats) TIMED_LAUNCH_ON(sx, 0, hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(BLOCK), ldsBytes, sx, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
+                else TIMED_LAUNCH_ON(sx, 0, hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(BLOCK), ldsBytes, sx, c->sc, pr.st, c->dQueue[pr.iter & 1], pr.iter, (int)pr.launched, c->dCtl));
             } else {
-                TIMED_LAUNCH(0, launchExtendPersist(c, pr));
+                TIMED_LAUNCH_ON(sx, 0, launchExtendPersist(c, pr));
             }
-#define SHADE_ARGS dim3(std::max(1, (int)((pr.launched + SHADE_BLOCK - 1) / SHADE_BLOCK))), dim3(SHADE_BLOCK), 0, s, c->sc, b, c->dFc, pr.st, c->dQueue[pr.iter & 1], c->dQueue[(pr.iter + 1) & 1], pr.iter, (int)pr.launched, c->dCtl
+            if (part) { HIP_TRY(hipEventRecord(c->evExt, sx)); HIP_TRY(hipStreamWaitEvent(ss, c->evExt, 0)); }
+#define SHADE_ARGS dim3(std::max(1, (int)((pr.launched + SHADE_BLOCK - 1) / SHADE_BLOCK))), dim3(SHADE_BLOCK), 0, ss, c->sc, b, c->dFc, pr.st, c->dQueue[pr.iter & 1], c->dQueue[(pr.iter + 1) & 1], pr.iter, (int)pr.launched, c->dCtl
             // kernel variant: transmissive materials present / statistics on / RAYTRACING == 0 / texture-mapped materials present
             // (T: index-stack encoding of the path state — 0 no transmissive material, 3 / 8 bits per slot)
-#define SHADE_V(T, S, D, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
-#define SHADE_F(T, X) TIMED_LAUNCH(1, hipLaunchKernelGGL((k_shade<T, false, false, X, true>), SHADE_ARGS))
+#define SHADE_V(T, S, D, X) TIMED_LAUNCH_ON(ss, 1, hipLaunchKernelGGL((k_shade<T, S, D, X>), SHADE_ARGS))
+#define SHADE_F(T, X) TIMED_LAUNCH_ON(ss, 1, hipLaunchKernelGGL((k_shade<T, false, false, X, true>), SHADE_ARGS))
             // (the relaxed numeric contract, pt_set_option 16: path tracing without statistics only; everything else keeps the exact kernels)
 #define SHADE_S(T, D, X) do { if (c->countStats) SHADE_V(T, true, D, X); else if (fastNow && !(D)) SHADE_F(T, X); else SHADE_V(T, false, D, X); } while (0)
 #define SHADE_X(T, D) do { if (c->anyMaps) SHADE_S(T, D, true); else SHADE_S(T, D, false); } while (0)
@@ -1585,9 +1618,11 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
             else if (c->niBits == 8) SHADE_X(8, false);
             else if (c->niBits == 32) SHADE_X(32, false);
             else SHADE_X(0, false);
+            if (part) { HIP_TRY(hipEventRecord(c->evShade, ss)); HIP_TRY(hipStreamWaitEvent(sx, c->evShade, 0)); }
             c->iter = (c->iter + 1) & 0x3fffffff;
             iters++;
         }
+        if (part) HIP_TRY(hipStreamWaitEvent(s, c->evShade, 0));
         HIP_TRY(hipGetLastError());                                // a failed launch surfaces here, not as "did not drain"
         if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
         // has the oldest batch been handed out completely (as of the previous look)?  then see whether it is still in flight
@@ -1907,6 +1942,9 @@ int pt_destroy(pt_ctx* c) {
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
     if (c->hSeeds) hipHostFree(c->hSeeds);
     for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (c->sExt) hipStreamDestroy(c->sExt);
+    if (c->sShade) hipStreamDestroy(c->sShade);
+    for (hipEvent_t e : {c->evExt, c->evShade, c->evHost}) if (e) hipEventDestroy(e);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return PT_OK;
@@ -2252,6 +2290,7 @@ int pt_set_option(pt_ctx* c, int option, int64_t value) {
         case 16: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "numeric contract: 0 exact (bit-identical to the oracle), 1 relaxed (hardware rcp/rsq/sqrt/log/cos; RMSE <= 1e-3)"); c->fastContract = value != 0; return PT_OK;
         case 19: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "node records of the hand-written kernel: -1 automatic, 0 80-B sign-ordered, 1 64-B"); c->asmNodeLayout = (int)value; c->sceneDirty = true; return PT_OK;
         case 18: if (value < 0 || value > 2) return fail(PT_ERR_ARG, "index-stack encoding: 0 automatic, 1 at least 8-bit codes, 2 the floats themselves"); c->forceNiBits8 = (int)value; c->sceneDirty = true; return PT_OK;
+        case 21: if (value < 0 || value > 7) return fail(PT_ERR_ARG, "spatial partition: eighths of every XCD's CUs for the intersect kernel (0 = off: both kernels on all CUs)"); c->cuPartition = (int)value; return PT_OK;
         case 20: if (value != 0 && value != 1) return fail(PT_ERR_ARG, "per-ray cull of the object loop (more than 8 BVHs): 0 off, 1 on"); c->asmNoRootCull = value == 0; c->sceneDirty = true; return PT_OK;
         case 17: if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(PT_ERR_ARG, "block size of the hand-written kernel: 0 automatic, 256, 512 or 1024"); c->asmTpb = (int)value; return PT_OK;
         case 14: if (value < -1 || value > 1) return fail(PT_ERR_ARG, "main loop of the hand-written kernel: -1 automatic, 0 phase-voting, 1 fused trip"); c->asmLoop = (int)value; return PT_OK;

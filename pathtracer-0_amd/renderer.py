@@ -19,7 +19,7 @@ COUNTERS = ["segments", "nodes", "tritests", "hitupd", "samples", "boxtests", "i
 KERNELS = {"extend": 0, "shade": 1, "generate": 2, "accumulate": 3}
 OPTIONS = {"path_slots": 0, "count_stats": 1, "lds_budget": 2, "none_min": 3, "extend_mode": 4, "extend_tpb": 5, "extend_cache_bytes": 6,
            "refill_min": 7, "extend_blocks_per_cu": 8, "inner_keep_eighths": 9, "bfs_nodes": 10, "stack_mode": 11,
-           "query_asm_eligible": 12, "query_asm_launches_above": 13, "asm_loop": 14, "numeric_contract": 16, "asm_tpb": 17, "index_stack_8bit": 18, "asm_node_layout": 19, "asm_root_cull": 20}
+           "query_asm_eligible": 12, "query_asm_launches_above": 13, "asm_loop": 14, "numeric_contract": 16, "asm_tpb": 17, "index_stack_8bit": 18, "asm_node_layout": 19, "asm_root_cull": 20, "cu_partition": 21}
 
 
 def hip_runtimes_mapped():
