@@ -3,7 +3,7 @@
 #   flag_ab.sh [-r ROUNDS] [-c "C3 C4"] [-t] [-s STEPS] "<flags A>" "<flags B>" ...      ("" = the defaults)   -t keeps the per-kernel HIP-event timing
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 ROUNDS=2; CFGS="C3"; TIMES=0; STEPS=6
-while getopts "r:c:ts:" o; do case $o in r) ROUNDS=$OPTARG;; c) CFGS=$OPTARG;; t) TIMES=1;; s) STEPS=$OPTARG;; esac; done
+while getopts ":r:c:ts:" o; do case $o in r) ROUNDS=$OPTARG;; c) CFGS=$OPTARG;; t) TIMES=1;; s) STEPS=$OPTARG;; esac; done
 shift $((OPTIND-1))
 cd $R
 NR=""; [ $TIMES = 0 ] && NR="--no-roofline"

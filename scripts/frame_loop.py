@@ -13,7 +13,7 @@ import ptimport  # noqa: E402
 pt = ptimport.load()
 from pathtracer_0_amd import renderer, scenes  # noqa: E402
 
-W, H, N = 1920, 1080, 64
+W, H, N = 1920, 1080, int(os.environ.get("FRAMES", "64"))
 wl = scenes.build("C3", W, H)
 # usage: frame_loop.py [streams] [path_slots]   (streams > 1: pt_create_multi with GPU 0 listed that many times)
 streams = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -42,14 +42,20 @@ def per_frame_async():
 
 
 def one_batch():
-    r.render_batch(1, seeds[:32]); r.render_batch(33, seeds[32:])
+    for k in range(0, N, 32):
+        r.render_batch(k + 1, seeds[k:k + 32])
+
+
+def batches_async():
+    for k in range(0, N, 32):
+        r.render_batch_async(k + 1, seeds[k:k + 32])
 
 
 res = {}
-for name, fn in (("pt_render per frame", per_frame_sync), ("pt_render_batch_async per frame", per_frame_async), ("two 32-frame batches", one_batch)):
+for name, fn in (("pt_render per frame", per_frame_sync), ("pt_render_batch_async per frame", per_frame_async), ("32-frame batches (synchronous)", one_batch), ("32-frame batches (asynchronous)", batches_async)):
     dt, img = timed(fn)
     res[name] = img
     print(f"{name:34s} {N} frames x 8 spp at {W}x{H}: {dt * 1e3 / N:7.2f} ms/frame  {W * H * 8 * N / dt / 1e6:8.1f} Msamples/s", flush=True)
 imgs = list(res.values())
-print("all three images bit-identical:", all((imgs[0] == im).all() for im in imgs[1:]))
+print("all images bit-identical:", all((imgs[0] == im).all() for im in imgs[1:]))
 r.close()

@@ -24,5 +24,5 @@ print("PARITY_OK")
 PY
 tail -3 $O/parity.txt
 grep -q PARITY_OK $O/parity.txt || exit 1
-bash scripts/flag_ab.sh -r 2 -c "C3 C4" -t "" "--cu-partition 6" "--cu-partition 5" "--cu-partition 7" "--cu-partition 4" 2>&1 | tee $O/ab.txt
-bash scripts/flag_ab.sh -r 1 -c "C3" -t "--cu-partition 6 --extend-blocks-per-cu 6" "--cu-partition 6 --streams 3" "--cu-partition 5 --streams 3" "--streams 1" "--streams 1 --cu-partition 6" 2>&1 | tee -a $O/ab.txt
+bash scripts/flag_ab.sh -r 2 -c "C3 C4" -t -- "" "--cu-partition 6" "--cu-partition 5" "--cu-partition 7" "--cu-partition 4" 2>&1 | tee $O/ab.txt
+bash scripts/flag_ab.sh -r 1 -c "C3" -t -- "--cu-partition 6 --extend-blocks-per-cu 6" "--cu-partition 6 --streams 3" "--cu-partition 5 --streams 3" "--streams 1" "--streams 1 --cu-partition 6" 2>&1 | tee -a $O/ab.txt
