@@ -113,6 +113,28 @@ def test_c_client_renders_what_the_python_wrappers_render(pt, renderer_mod, tmp_
     assert np.all(img[..., 3] == frames)
 
 
+@pytest.mark.gpu
+def test_c_host_runs_the_bench_schedule(pt, renderer_mod, tmp_path):
+    """tests/c/bench_client.c: bench.py's schedule (pt_next_image, asynchronous batches, the image gathered two steps later, two streams behind ONE context)
+    driven from plain C on the HIP runtime the library links by itself — the process a Java / C host is (scripts/c_host_bench.py times it at full size for
+    INTEGRATION.md section 3).  The last image equals the same frames rendered through the Python wrappers."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("c_host_bench", os.path.join(ROOT, "scripts", "c_host_bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    W, H, fps = 192, 108, 3
+    d = json.loads(m.run("C3", steps=4, warmup=1, streams=2, fps=fps, W=W, H=H, workdir=str(tmp_path)))
+    assert d["value"] > 0 and d["count"] == fps and "libamdhip64" in d["hip_runtime"] and "torch" not in d["hip_runtime"]
+    wl = pt.scenes.build("C3", W, H)
+    r = renderer_mod.Renderer(W, H)
+    r.load_workload(wl); r.reset_frame(); r.render_batch(1, [pt.scenes.frame_seed(f) for f in range(1, 1 + fps)])
+    img = r.read_frame(); r.close()
+    h = 1469598103934665603
+    for byte in img.tobytes():
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert "%016x" % h == d["fnv1a"]
+
+
 def test_gather_layout_roundtrip(pt):
     """The bookkeeping of the one collective: every rank's packed accumulator (pt_shard_map order, padded to pt_shard_slots) laid
     rank-major — what ncclGather delivers on the root — and scattered through the concatenated maps (k_unshard's contract) is the image."""
