@@ -87,6 +87,7 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned long long cnt[8];   // PT_CNT_* (device side: segments, nodes, tritests, hitupd, samples, boxtests)
     unsigned qCount[64];    // entries of queue (j&1) at [32*(j&1)]: two words, 128 B apart
     unsigned long long dbg[16];  // developer build (-DPT_PHASE_STATS): trips and active lanes per phase of the intersect kernel
+    unsigned busy[8];       // k_scan_inflight: busy[k] = a live slot still works on a frame of the k-th oldest unaccumulated batch
 #if defined(PT_PHASE_STATS) || defined(PT_WAVE_STAMPS)
     unsigned long long waveEnd[8192];   // s_memrealtime (100 MHz) at which each wave of the last intersect launch finished
     unsigned long long waveStart[8192]; // ... and started
@@ -792,11 +793,18 @@ __global__ void __launch_bounds__(64) k_debug_heatmap(DevScene sc, Batch b, cons
     frame[slot] = F;
 }
 
-// Is any live slot still working on a stream frame below fEnd (the oldest batch that has not been accumulated yet)?
-__global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, unsigned fEnd, Control* ctl) {
+// Which of the (up to 8) oldest batches that have not been accumulated yet does a live slot still work on?  ends.f[k] = first stream frame BEHIND the k-th of
+// them (ascending): a live slot on frame f keeps the first batch with f < ends.f[k] busy.  One pass over the flags per host poll.
+struct ScanEnds { unsigned f[8]; int n; };
+__global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, ScanEnds ends, Control* ctl) {
     unsigned i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= (unsigned)nSlots) return;
-    if ((__float_as_uint(st.G1[i].w) & FL_ALIVE) && st.J[i].x < fEnd) ctl->oldestBusy = 1u;
+    if (!(__float_as_uint(st.G1[i].w) & FL_ALIVE)) return;
+    const unsigned f = st.J[i].x;
+    if (f >= ends.f[ends.n - 1]) return;
+    int k = 0;
+    while (f >= ends.f[k]) k++;
+    ctl->busy[k] = 1u;
 }
 
 // fragColor -> UNORM8 framebuffer -> glReadPixels(GL_RGB) -> Java signed-byte packing -> vertical flip (dispatch.java:804-833)
@@ -829,7 +837,7 @@ __global__ void k_unshard(const float4* gathered, const int* maps, int nSlots, i
 }
 
 __global__ void k_init_control(Control* ctl) {                     // a new frame stream: job ids restart at 0
-    ctl->nextJob = 0; ctl->jobEnd = 0; ctl->needRevive = 1; ctl->oldestBusy = 0;
+    ctl->nextJob = 0; ctl->jobEnd = 0; ctl->needRevive = 1; ctl->oldestBusy = 0; for (int k = 0; k < 8; k++) ctl->busy[k] = 0;
     for (int k = 0; k < 4; k++) ctl->exhausted[k] = 0;
     ctl->qCount[0] = 0; ctl->qCount[32] = 0;
 }
@@ -911,7 +919,11 @@ struct pt_ctx {
     unsigned streamFrames = 0, streamJobs = 0, lastNextJob = 0, lastDelta = 0, launched = 0; int lastCheck = 24, iter = 0; bool draining = false;
     uint64_t lastSubmitJobs = 0, jobsThisImage = 0, jobsPerImage = 0;      // what the last submission added; jobs submitted for the current / the previous FRAME image
     FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
-    Control* hCtl = nullptr;        // pinned copy for the host's polls
+    // The host polls the device's scheduler words once per GROUP of iterations: a group = its launches + (a scan of the oldest batches) + a copy of Control into
+    // the group's pinned snapshot + an event.  Up to two groups are in flight: the host looks at a snapshot when its event has fired, so the stream always holds
+    // the next group's launches while one runs, and an asynchronous submission never waits for the iterations it started (pump).
+    struct Group { hipEvent_t ev = nullptr; Control* h = nullptr; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; };
+    Group grp[2]; int grpHead = 0, grpCount = 0; bool scanInFlight = false; unsigned submitEpoch = 0;
     FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr;   // pinned staging (hSeeds: ring like dSeeds)
     // options / stats
     bool countStats = false, timing = false;
@@ -1550,8 +1562,47 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // PUMP_IDLE: every batch retired.  PUMP_ISSUED: the jobs not yet handed out fit into roughly one more group of iterations
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
 // rows are still owned by unretired batches.
+// The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
+int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
+    pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
+    if (!wait) {
+        const hipError_t q = hipEventQuery(g.ev);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return fail(PT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+    } else if (hipEventSynchronize(g.ev) != hipSuccess) return fail(PT_ERR_HIP, "hipEventSynchronize failed (a kernel of the wavefront stream faulted?)");
+    c->grpCount--;
+    if (g.nScan) c->scanInFlight = false;
+    if (discard) return 1;
+    const Control& h = *g.h;
+    c->lastDelta = h.nextJob >= c->lastNextJob ? h.nextJob - c->lastNextJob : 0; c->lastCheck = g.check;
+    c->lastNextJob = h.nextJob;
+    bool allDead = false;
+    if (g.epoch == c->submitEpoch) {                               // nothing was submitted since the group was launched: its view of the tail is the stream's
+        if (h.exhausted[(g.iterEnd + 3) & 3]) {                    // the iteration after the group reads the queue: its count is exact (and only falls from there)
+            c->draining = true;
+            c->launched = h.qCount[32 * (g.iterEnd & 1)];
+            allDead = c->launched == 0;
+        } else if (h.nextJob >= c->streamJobs) {
+            c->draining = true;                                    // jobs just ran out; the queue starts within two iterations
+        }
+    }
+    int rc;
+    if (allDead) { while (!c->pending.empty()) if ((rc = retireFront(c))) return rc; }
+    else if (g.nScan && !c->pending.empty() && c->pending.front().f0 == g.scanF0) {
+        for (int k = 0; k < g.nScan && !c->pending.empty() && !h.busy[k]; k++) if ((rc = retireFront(c))) return rc;      // in u_frameCount order, oldest first
+    }
+    return 1;
+}
+int drainGroups(pt_ctx* c, bool discard) {
+    while (c->grpCount > 0) { const int r = processOldestGroup(c, true, discard); if (r < 0) return r; }
+    return 0;
+}
+
+// PUMP_IDLE: every batch retired.  PUMP_ISSUED: the jobs not yet handed out fit into roughly one more group of iterations
+// (never waits for the pool to run dry, and never for the group it starts).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
+// rows are still owned by unretired batches.
 int pump(pt_ctx* c, PumpUntil until, int arg) {
-    if (c->pending.empty()) return 0;
+    if (c->pending.empty()) return drainGroups(c, true);          // (groups launched before the last batch retired ran over a dead pool: nothing to learn from them)
     hipStream_t s = c->stream;
     { int rc = ensurePartition(c); if (rc) return rc; }
     const bool part = c->sExt != nullptr && s == c->ownStream;
@@ -1577,23 +1628,22 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     // every job retires within SAMPLE_RES * ceil(MAX_BOUNCES) iterations of being started, and a slot runs at most
     // ceil(jobs / slots) jobs back to back: a pump that exceeds this bound (x2) is a scheduler bug, not work
     const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + (uint64_t)N;
-    const uint64_t maxIters = 2 * ((outstanding + N - 1) / N + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64;
+    const uint64_t maxIters = 2 * ((outstanding + N - 1) / N + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64 + 48;
     uint64_t iters = 0;
-    bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going: about as many iterations as consume what it added
-    while (kick || !satisfied()) {
-        if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
-        // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
-        // The host only polls: while jobs remain the end is at least one whole job (>= SAMPLE_RES iterations) away, so it looks
-        // every 24 iterations, in the tail every 8; each look shrinks the launch grids to the live count.
+    // One group: its iterations, a scan of the oldest batches once they have been handed out completely, the snapshot of Control, the event.
+    // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
+    // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
+    // The host only looks: while jobs remain the end is at least one whole job (>= SAMPLE_RES iterations) away, so a group is
+    // 24 iterations, in the tail 8; each look shrinks the launch grids to the live count.
+    auto launchGroup = [&](bool kick) -> int {
         int CHECK = c->draining ? 8 : 24;
         if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
-            int64_t left = (int64_t)c->streamJobs - (int64_t)c->lastNextJob - (int64_t)c->lastDelta / 2 - (int64_t)arg;
-            int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));
+            const int64_t backlog = (int64_t)c->streamJobs - (int64_t)c->lastNextJob;      // (as of the last look: the groups in flight have taken some of it since)
+            const int64_t left = backlog - (int64_t)c->lastDelta / 2 - (int64_t)arg;
+            const int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));
             if (left > 0) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, left / perIter));
-            else if (kick) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, (int64_t)c->lastSubmitJobs / perIter));
+            else if (kick) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, std::max<int64_t>(backlog, (int64_t)c->lastSubmitJobs) / perIter));
         }
-        kick = false;
         if (part) { HIP_TRY(hipEventRecord(c->evHost, s)); HIP_TRY(hipStreamWaitEvent(sx, c->evHost, 0)); }      // what `s` holds (submission, revive, accumulate) comes first
         for (int k = 0; k < CHECK; k++) {
             PoolRun pr; pr.stream = sx; pr.st = c->st; pr.launched = c->launched; pr.iter = c->iter;
@@ -1625,31 +1675,41 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (part) HIP_TRY(hipStreamWaitEvent(s, c->evShade, 0));
         HIP_TRY(hipGetLastError());                                // a failed launch surfaces here, not as "did not drain"
         if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
-        // has the oldest batch been handed out completely (as of the previous look)?  then see whether it is still in flight
-        const bool scan = !c->pending.empty() && c->lastNextJob >= c->pending.front().jobEnd;
-        if (scan) {
-            HIP_TRY(hipMemsetAsync(&c->dCtl->oldestBusy, 0, 4, s));
-            hipLaunchKernelGGL(k_scan_inflight, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, c->st, N, c->pending.front().f0 + (unsigned)c->pending.front().nFrames, c->dCtl);
+        pt_ctx::Group& g = c->grp[c->grpHead];
+        g.check = CHECK; g.iterEnd = c->iter; g.epoch = c->submitEpoch; g.nScan = 0;
+        // have the oldest batches been handed out completely (as of the last look)?  then see which of them are still in flight (one scan in flight at a time)
+        if (!c->scanInFlight) {
+            ScanEnds ends{};
+            for (const auto& e : c->pending) {
+                if (ends.n == 8 || c->lastNextJob < e.jobEnd) break;
+                ends.f[ends.n++] = e.f0 + (unsigned)e.nFrames;
+            }
+            if (ends.n) {
+                HIP_TRY(hipMemsetAsync(c->dCtl->busy, 0, sizeof(c->dCtl->busy), s));
+                hipLaunchKernelGGL(k_scan_inflight, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, c->st, N, ends, c->dCtl);
+                g.nScan = ends.n; g.scanF0 = c->pending.front().f0; c->scanInFlight = true;
+            }
         }
-        HIP_TRY(hipMemcpyAsync(c->hCtl, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        const Control& h = *c->hCtl;
-        c->lastDelta = h.nextJob >= c->lastNextJob ? h.nextJob - c->lastNextJob : 0; c->lastCheck = CHECK;
-        c->lastNextJob = h.nextJob;
-        bool allDead = false;
-        if (h.exhausted[(c->iter + 3) & 3]) {                      // the next iteration reads the queue: its count is exact
-            c->draining = true;
-            c->launched = h.qCount[32 * (c->iter & 1)];
-            allDead = c->launched == 0;
-        } else if (h.nextJob >= c->streamJobs) {
-            c->draining = true;                                    // jobs just ran out; the queue starts within two iterations
-        }
-        int rc;
-        if (allDead) { while (!c->pending.empty()) if ((rc = retireFront(c))) return rc; }
-        else if (scan && !h.oldestBusy) { if ((rc = retireFront(c))) return rc; }
+        HIP_TRY(hipMemcpyAsync(g.h, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(g.ev, s));
+        c->grpHead = (c->grpHead + 1) % 2; c->grpCount++;
+        return 0;
+    };
+    int rc;
+    bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going: about as many iterations as consume what it added
+    while (c->grpCount > 0 && (rc = processOldestGroup(c, false, false)) != 0) if (rc < 0) return rc;      // whatever has finished since the last call
+    for (;;) {
+        const bool want = kick || !satisfied();
+        if (!want) break;
+        if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
+        const int room = c->draining ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
+        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; continue; }
+        if (kick) { kick = false; continue; }                     // two groups are on their way already: the submission rides behind them
+        if ((rc = processOldestGroup(c, true, false)) < 0) return rc;
     }
     c->hostCnt[PT_CNT_ITERATIONS] += iters;
     c->hostCnt[PT_CNT_EXTEND_LAUNCHES] += iters;
+    if (until != PUMP_ISSUED) return drainGroups(c, c->pending.empty());      // synchronous callers leave nothing behind them
     return 0;
 }
 
@@ -1734,6 +1794,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         hipLaunchKernelGGL(k_frame_setup, dim3(1), dim3(64), 0, s, c->sc, c->dFrameIn, c->dFc, c->dEllip);
         hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl);
         HIP_TRY(hipMemsetAsync(c->st.G1, 0, (size_t)c->poolActive * 16, s));       // every slot dead
+        if ((rc = drainGroups(c, true))) return rc;
         c->streamFrames = 0; c->streamJobs = 0; c->lastNextJob = 0; c->lastDelta = 0; c->lastCheck = 24; c->iter = 0;
     } else if ((int)(c->streamFrames - c->pending.front().f0) + nFrames > c->ringFrames) {
         if ((rc = pump(c, PUMP_RING, c->ringFrames - nFrames))) return rc;        // wait for ring rows
@@ -1778,6 +1839,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     pt_ctx::Entry e; e.jobEnd = c->streamJobs; e.f0 = f0; e.nFrames = nFrames; e.firstFrame = firstFrame; e.image = c->curImage;
     c->pending.push_back(e);
     c->draining = false; c->launched = (unsigned)N;              // (if the pool had run dry, k_submit dropped the tail queue)
+    c->submitEpoch++;                                            // the groups in flight were launched for another tail: their view of it no longer counts
     HIP_TRY(hipGetLastError());
     // asynchronous: come back while the backlog of jobs not yet handed out is below what keeps the largest pool fed (2^23 * 8/5)
     if (async) return pump(c, PUMP_ISSUED, c->poolSlots == 0 ? 14000000 : 0);
@@ -1836,7 +1898,7 @@ int initContext(pt_ctx* c, int width, int height, int shard_rank, int shard_coun
     HIP_TRY(hipMalloc((void**)&c->dFc, sizeof(FrameConst)));
     HIP_TRY(hipMalloc((void**)&c->dCtl, sizeof(Control)));
     HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
-    HIP_TRY(hipHostMalloc((void**)&c->hCtl, sizeof(Control), hipHostMallocDefault));
+    for (auto& g : c->grp) { HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(Control), hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming)); }
     HIP_TRY(hipHostMalloc((void**)&c->hFrameIn, sizeof(FrameIn), hipHostMallocDefault));
     return 0;
 }
@@ -1938,7 +2000,7 @@ int pt_destroy(pt_ctx* c) {
     void* ptrs[] = {c->dNiTable, c->st.J, c->dNodes80, c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
-    if (c->hCtl) hipHostFree(c->hCtl);
+    for (auto& g : c->grp) { if (g.h) hipHostFree(g.h); if (g.ev) hipEventDestroy(g.ev); }
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
     if (c->hSeeds) hipHostFree(c->hSeeds);
     for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
