@@ -922,8 +922,9 @@ struct pt_ctx {
     // The host polls the device's scheduler words once per GROUP of iterations: a group = its launches + (a scan of the oldest batches) + a copy of Control into
     // the group's pinned snapshot + an event.  Up to two groups are in flight: the host looks at a snapshot when its event has fired, so the stream always holds
     // the next group's launches while one runs, and an asynchronous submission never waits for the iterations it started (pump).
-    struct Group { hipEvent_t ev = nullptr; Control* h = nullptr; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; };
+    struct Group { hipEvent_t ev = nullptr; Control* h = nullptr; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; int64_t predicted = 0; };
     Group grp[2]; int grpHead = 0, grpCount = 0; bool scanInFlight = false; unsigned submitEpoch = 0;
+    int64_t inflightPredicted = 0;  // jobs the groups in flight are expected to hand out (iterations x the rate of the last look): lastNextJob is as old as the oldest of them
     FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr;   // pinned staging (hSeeds: ring like dSeeds)
     // options / stats
     bool countStats = false, timing = false;
@@ -1572,6 +1573,7 @@ int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     } else if (hipEventSynchronize(g.ev) != hipSuccess) return fail(PT_ERR_HIP, "hipEventSynchronize failed (a kernel of the wavefront stream faulted?)");
     c->grpCount--;
     if (g.nScan) c->scanInFlight = false;
+    c->inflightPredicted = std::max<int64_t>(0, c->inflightPredicted - g.predicted);
     if (discard) return 1;
     const Control& h = *g.h;
     c->lastDelta = h.nextJob >= c->lastNextJob ? h.nextJob - c->lastNextJob : 0; c->lastCheck = g.check;
@@ -1619,7 +1621,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (c->pending.empty()) return true;
         switch (until) {
             case PUMP_IDLE: return false;
-            case PUMP_ISSUED: return c->draining || (int64_t)c->streamJobs - (int64_t)c->lastNextJob <= std::max<int64_t>((int64_t)c->lastDelta, (int64_t)arg);
+            case PUMP_ISSUED: return c->draining || (int64_t)c->streamJobs - (int64_t)c->lastNextJob - c->inflightPredicted <= std::max<int64_t>((int64_t)c->lastDelta, (int64_t)arg);
             case PUMP_IMAGE: for (const auto& e : c->pending) if (e.image == arg) return false; return true;
             case PUMP_RING: return (int)(c->streamFrames - c->pending.front().f0) <= arg;
         }
@@ -1637,12 +1639,12 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     // 24 iterations, in the tail 8; each look shrinks the launch grids to the live count.
     auto launchGroup = [&](bool kick) -> int {
         int CHECK = c->draining ? 8 : 24;
+        const int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));      // jobs handed out per iteration at the last look
         if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
-            const int64_t backlog = (int64_t)c->streamJobs - (int64_t)c->lastNextJob;      // (as of the last look: the groups in flight have taken some of it since)
+            const int64_t backlog = std::max<int64_t>(0, (int64_t)c->streamJobs - (int64_t)c->lastNextJob - c->inflightPredicted);      // as of the last look, less what the groups in flight take
             const int64_t left = backlog - (int64_t)c->lastDelta / 2 - (int64_t)arg;
-            const int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));
             if (left > 0) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, left / perIter));
-            else if (kick) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, std::max<int64_t>(backlog, (int64_t)c->lastSubmitJobs) / perIter));
+            else if (kick) CHECK = (int)std::max<int64_t>(1, std::min<int64_t>(CHECK, std::max<int64_t>(backlog, (int64_t)c->lastSubmitJobs) / perIter - 2));      // (two iterations' worth stay behind: later submissions sit BEHIND this group in the stream, and a pull that comes back empty sends the pool into its tail)
         }
         if (part) { HIP_TRY(hipEventRecord(c->evHost, s)); HIP_TRY(hipStreamWaitEvent(sx, c->evHost, 0)); }      // what `s` holds (submission, revive, accumulate) comes first
         for (int k = 0; k < CHECK; k++) {
@@ -1677,6 +1679,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
         pt_ctx::Group& g = c->grp[c->grpHead];
         g.check = CHECK; g.iterEnd = c->iter; g.epoch = c->submitEpoch; g.nScan = 0;
+        g.predicted = c->lastDelta > 0 ? (int64_t)CHECK * perIter : 0; c->inflightPredicted += g.predicted;
         // have the oldest batches been handed out completely (as of the last look)?  then see which of them are still in flight (one scan in flight at a time)
         if (!c->scanInFlight) {
             ScanEnds ends{};
@@ -1795,6 +1798,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         hipLaunchKernelGGL(k_init_control, dim3(1), dim3(1), 0, s, c->dCtl);
         HIP_TRY(hipMemsetAsync(c->st.G1, 0, (size_t)c->poolActive * 16, s));       // every slot dead
         if ((rc = drainGroups(c, true))) return rc;
+        c->inflightPredicted = 0;
         c->streamFrames = 0; c->streamJobs = 0; c->lastNextJob = 0; c->lastDelta = 0; c->lastCheck = 24; c->iter = 0;
     } else if ((int)(c->streamFrames - c->pending.front().f0) + nFrames > c->ringFrames) {
         if ((rc = pump(c, PUMP_RING, c->ringFrames - nFrames))) return rc;        // wait for ring rows
@@ -1803,12 +1807,13 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     // a stream fed in small batches (the reference draws ONE frame per call) started with a small pool: let it grow with the backlog
     bool grown = false;
     if (join && async && c->poolSlots == 0) {
-        const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + nJobs64;
+        const uint64_t outstanding = (uint64_t)std::max<int64_t>(0, (int64_t)c->streamJobs - (int64_t)std::min<uint64_t>(c->lastNextJob, c->streamJobs) - c->inflightPredicted) + nJobs64;
         size_t target = std::min<size_t>(std::max<size_t>(outstanding * 5 / 8, (size_t)1 << 20), (size_t)1 << 23);
         // an image is cheapest to finish two images later (pt_finish_image): keep an image's jobs worth several pool turnovers
         if (c->jobsPerImage) target = std::min<size_t>(target, std::max<size_t>((size_t)(c->jobsPerImage * 5 / 8), (size_t)1 << 20));
         target = std::min<size_t>((target + BLOCK - 1) / BLOCK * BLOCK, (size_t)c->allocSlots);
-        if (target > (size_t)c->poolActive + (size_t)c->poolActive / 4) {
+        const size_t cap = std::min<size_t>((size_t)1 << 23, (size_t)c->allocSlots);
+        if (target > (size_t)c->poolActive + (size_t)c->poolActive / 4 || (target >= cap && target > (size_t)c->poolActive)) {      // (the last step to the largest pool may be a small one)
             HIP_TRY(hipMemsetAsync(c->st.G1 + c->poolActive, 0, (target - (size_t)c->poolActive) * 16, s));      // the new slots are dead
             c->poolActive = (int)target;
             grown = true;
