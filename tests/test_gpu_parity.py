@@ -583,6 +583,48 @@ def test_write_frame_resumes_an_accumulation(pt, oracle, renderer_mod, form):
     assert_same(got, ref)
 
 
+@pytest.mark.parametrize("streams,opts", [(1, {}), (2, {}), (2, {"cu_partition": 4}), (1, {"path_slots": 4096})])
+def test_one_draw_per_frame_left_in_flight(pt, oracle, renderer_mod, streams, opts):
+    """The reference's call pattern (dispatch.java:693-705: one glDrawArrays per frame, nothing waited for): 100 frames submitted ONE per pt_render_batch_async call.
+    The scheduler keeps two groups of iterations in flight and looks at their snapshots when their events have fired, retires up to eight batches per look, makes the
+    caller wait for ring rows beyond 64 frames in flight, and lets a second image start underneath — the accumulator must equal the same frames as ONE batch and the oracle's.
+    (cu_partition: the CU-masked stream pair of profiles/r06_c_cu_partition.txt, an option that is not the default.)"""
+    W, H, N = 64, 36, 100
+    wl = pt.scenes.build("C3", W, H)
+    seeds = seeds_for(pt, 1, N)
+    make = (lambda: renderer_mod.Renderer(W, H, devices=[0] * streams)) if streams > 1 else (lambda: renderer_mod.Renderer(W, H))
+    r = make()
+    for k, v in opts.items():
+        r.set_option(k, v)
+    r.load_workload(wl); r.reset_frame()
+    for f in range(N):
+        r.render_batch_async(f + 1, seeds[f:f + 1])
+    r.next_image()                                            # a second image underneath the first one's last paths
+    for f in range(3):
+        r.render_batch_async(f + 1, seeds[f:f + 1])
+    second = r.read_frame().copy()
+    first = image_of_age(renderer_mod, r, 1)
+    r.close()
+    r = make(); r.load_workload(wl); r.reset_frame(); r.render_batch(1, seeds)
+    whole = r.read_frame().copy(); r.reset_frame(); r.render_batch(1, seeds[:3]); three = r.read_frame().copy(); r.close()
+    assert np.array_equal(first.view(np.uint32), whole.view(np.uint32)) and np.all(first[..., 3] == N)
+    assert np.array_equal(second.view(np.uint32), three.view(np.uint32))
+    ref, _ = oracle.render_frames(oracle.Scene.from_workload(wl), W, H, 1, 3, seeds[:3], nthreads=8)
+    assert_same(second, ref)
+
+
+def image_of_age(renderer_mod, r, age):
+    """the FRAME image `age` pt_next_image calls ago, gathered and copied to the host (hipMemcpy of the ONE runtime this process has mapped)"""
+    import ctypes
+    ptr = r.gather_image(age)
+    r.stream_wait()
+    out = np.zeros((r.H, r.W, 4), np.float32)
+    hip = ctypes.CDLL(renderer_mod.hip_runtime_info()["path"])
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(out.ctypes.data, ptr, out.nbytes, 2) == 0
+    return out
+
+
 def test_sharding_invariance(pt, oracle, renderer_mod):
     """K10: 1 vs 2/4 tile shards give bit-identical framebuffers (RNG keyed on the global pixel index)"""
     W, H = 96, 40
