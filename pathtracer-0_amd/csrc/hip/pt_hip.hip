@@ -1639,6 +1639,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     // 24 iterations, in the tail 8; each look shrinks the launch grids to the live count.
     auto launchGroup = [&](bool kick) -> int {
         int CHECK = c->draining ? 8 : 24;
+        if (kick && c->lastDelta == 0) CHECK = 4;                  // the first looks of a stream fed in small submissions come early: the pool grows with the backlog they report
         const int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));      // jobs handed out per iteration at the last look
         if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
             const int64_t backlog = std::max<int64_t>(0, (int64_t)c->streamJobs - (int64_t)c->lastNextJob - c->inflightPredicted);      // as of the last look, less what the groups in flight take
