@@ -1,15 +1,19 @@
 #!/bin/bash
-# measurement pass (usage: measure_all.sh [out-tag]): counter summaries (final kernels), kernel-trace stats, the bench lines, shard rehearsals
+# measurement pass (usage: measure_all.sh <out-tag> [pmc|rest|all]): counter summaries (final kernels) | kernel-trace stats, the bench lines, shard rehearsals, the drop-in call
+# pattern, the C host, fall-back paths, fuzz.  Two gpurun calls of at most 20 minutes each: `pmc` first (the bench lines of `rest` read profiles/pmc_*.json of THIS tree).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-measure}
+PART=${2:-all}
 mkdir -p $O
 cd $R
+if [ $PART != rest ]; then
 # 1. counters per configuration -> profiles/pmc_<cfg>.json (bench.py's roofline block reads them)
-FPS=32 bash scripts/pmc_all.sh ${1:-measure}/pmc_C3 C3 > $O/pmc_C3.log 2>&1; cp $O/pmc_C3/summary.json profiles/pmc_C3.json; echo "pmc C3 done"
-FPS=16 bash scripts/pmc_all.sh ${1:-measure}/pmc_C4 C4 > $O/pmc_C4.log 2>&1; cp $O/pmc_C4/summary.json profiles/pmc_C4.json; echo "pmc C4 done"
-FPS=4 bash scripts/pmc_all.sh ${1:-measure}/pmc_C5 C5 > $O/pmc_C5.log 2>&1; cp $O/pmc_C5/summary.json profiles/pmc_C5.json; echo "pmc C5 done"
-FPS=8 bash scripts/pmc_all.sh ${1:-measure}/pmc_C2 C2 > $O/pmc_C2.log 2>&1; cp $O/pmc_C2/summary.json profiles/pmc_C2.json; echo "pmc C2 done"
-FPS=4 bash scripts/pmc_all.sh ${1:-measure}/pmc_C6 C6 > $O/pmc_C6.log 2>&1; cp $O/pmc_C6/summary.json profiles/pmc_C6.json; echo "pmc C6 done"
+for c in ${PMC_CFGS:-C3 C4 C5 C2 C6}; do
+  case $c in C3) f=32;; C4) f=16;; C2) f=8;; *) f=4;; esac
+  FPS=$f bash scripts/pmc_all.sh ${1:-measure}/pmc_$c $c > $O/pmc_$c.log 2>&1; cp $O/pmc_$c/summary.json profiles/pmc_$c.json; echo "pmc $c done"
+done
+fi
+[ $PART = pmc ] && exit 0
 # 2. the driver's command
 timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_c3.json 2> $O/bench_default_c3.err; echo "bench rc=$?"
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_c3_untimed_kernels.json 2>/dev/null
@@ -41,6 +45,18 @@ for f in sorted(glob.glob("$O/bench_*.json")):
             d=json.loads(l); r=d.get("roofline",{})
             print(f.split("/")[-1], d["value"], "Ms/s", d["ms_per_step"], "ms/step", "frac", r.get("frac"), "hbm", (r.get("hbm") or {}).get("frac"), "shade", (r.get("shade") or {}).get("frac"), "parity", d.get("parity"))
 PY
-# 5. the launches the hand-written kernel does not take, and a fuzz campaign over the switches
+# 5. the drop-in call pattern (one draw per frame) and the C host on ROCm's own runtime beside the Python bench
+export GPU_MAX_HW_QUEUES=8
+for n in 64 256; do echo "== streams 2 FRAMES $n"; FRAMES=$n timeout -k 10 300 python3 scripts/frame_loop.py 2 0 2>&1 | grep -v amdgpu.ids; done | tee $O/frame_loop.txt
+echo "== streams 1 FRAMES 64" | tee -a $O/frame_loop.txt; FRAMES=64 timeout -k 10 300 python3 scripts/frame_loop.py 1 0 2>&1 | grep -v amdgpu.ids | tee -a $O/frame_loop.txt
+for k in 1 2; do
+  timeout -k 10 600 python3 scripts/c_host_bench.py --steps 20 --warmup 5 --streams 2 2>&1 | grep "^{" | tee -a $O/c_host.txt
+  timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python3 -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(json.dumps({'host': 'python bench.py', 'hip_runtime': d['hip_runtime'], 'ms_per_step': d['ms_per_step'], 'value': d['value']}))" | tee -a $O/c_host.txt
+done
+# 6. the launches the hand-written kernel does not take, and a fuzz campaign over the switches
 timeout -k 10 400 python3 scripts/fallback_paths.py 2>&1 | grep -v amdgpu.ids | tee $O/fallback_paths.txt
 timeout -k 10 600 python3 scripts/fuzz_campaign.py 70001 400 2>&1 | tail -3 | tee $O/fuzz.txt
