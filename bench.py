@@ -159,7 +159,10 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     unit_gc = UNIT_PEAK_GCYC
     td = ke["td_busy_cycles_per_segment"] * seg_rate / 1e9 if have_vmem else None
     ta = ke["ta_busy_cycles_per_segment"] * seg_rate / 1e9 if (ke and "ta_busy_cycles_per_segment" in ke) else None
-    ok = have_vmem and not stale
+    # the counters were collected in the default configuration (two streams per GPU: 256-thread intersect blocks over a 16 KB tile); a one-stream context runs 1024-thread
+    # blocks over a 32 KB tile, which make fewer L1 accesses per segment — its launches are not priced with another configuration's cycles per segment
+    same_cfg = streams > 1
+    ok = have_vmem and not stale and same_cfg
     out = {"bound": "vmem_divergent", "kernel": ext_kernel, "configuration": f"the timed region: {streams} stream(s) per GPU, {n_gpus} GPU(s)",
            "achieved": round(td, 1) if ok else None, "peak": unit_gc, "unit": "G TD-busy cycles/s", "frac": round(td / unit_gc, 4) if ok else None,
            "traffic": round(ke["hbm_bytes_per_segment"] * seg_per_launch) if ke and "hbm_bytes_per_segment" in ke else None,
@@ -177,9 +180,12 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
     if stale:
         out["note"] = ("COUNTERS STALE: " + prof_name + " was measured on other kernel sources (its hash differs from kernel_source_hash): every figure derived from it — frac, "
                        "hbm_frac, the sub-blocks' fractions — is withheld or provisional until scripts/pmc_all.sh has run on this tree.  ") + out["note"]
+    if have_vmem and not same_cfg:
+        out["note"] = ("ONE stream per GPU: the committed counters are those of the two-stream block configuration, so the top-level fraction is withheld; the directly measured busy "
+                       "shares of the kernel alone on the chip are under vmem.alone_on_the_chip.  ") + out["note"]
     if have_vmem:
-        out["vmem"] = {"td_busy": {"cycles_per_segment": ke["td_busy_cycles_per_segment"], "achieved": round(td, 1), "frac": round(td / unit_gc, 4)},
-                       "ta_busy": ({"cycles_per_segment": ke["ta_busy_cycles_per_segment"], "achieved": round(ta, 1), "frac": round(ta / unit_gc, 4)} if ta is not None else None),
+        out["vmem"] = {"td_busy": {"cycles_per_segment": ke["td_busy_cycles_per_segment"], "achieved": round(td, 1) if same_cfg else None, "frac": round(td / unit_gc, 4) if same_cfg else None},
+                       "ta_busy": ({"cycles_per_segment": ke["ta_busy_cycles_per_segment"], "achieved": round(ta, 1) if same_cfg else None, "frac": round(ta / unit_gc, 4) if same_cfg else None} if ta is not None else None),
                        "alone_on_the_chip": {k: ke.get(k) for k in ("ta_busy_frac_alone", "td_busy_frac_alone", "td_waiting_for_cache_frac_alone", "ta_addr_stalled_by_cache_frac_alone")},
                        "tag_lookups_per_vmem_inst": ke.get("tag_lookups_per_vmem_inst"), "l1_hit_rate": ke.get("l1_hit_rate"), "l2_round_trip_cycles": ke.get("l2_round_trip_cycles"),
                        "vmem_rd_per_segment": ke.get("vmem_rd_per_segment"), "provisional": bool(stale)}
@@ -216,8 +222,10 @@ def roofline_block(args, r, stats, samples, world, dt, value, sample_res, n_gpus
               "algorithmic_GBps": round(b_ext * rate / 1e9, 1)}
         if have_valu:
             al["valu_issue"] = {"achieved": round(ke["valu_per_segment"] * rate / 1e9, 1), "frac": round(ke["valu_per_segment"] * rate / 1e9 / VALU_PEAK_GINST, 4)}
-        if have_vmem:
-            al["td_busy"] = {"achieved": round(ke["td_busy_cycles_per_segment"] * rate / 1e9, 1), "frac": round(ke["td_busy_cycles_per_segment"] * rate / 1e9 / UNIT_PEAK_GCYC, 4)}
+        if have_vmem:      # measured directly: rocprofv3 serialises the kernels of a counter pass, so its busy shares ARE the kernel alone on the chip (in the block configuration of the pass)
+            al["td_busy"] = {"frac": ke.get("td_busy_frac_alone"), "ta_busy_frac": ke.get("ta_busy_frac_alone"),
+                             "note": "TD_TD_BUSY_sum / (256 x GRBM_GUI_ACTIVE / 8) of the counter pass (two-stream block configuration: 256-thread blocks, 16 KB tile); "
+                                     "no per-segment figure is applied to this pass's launches, whose 1024-thread blocks over a 32 KB tile make fewer L1 accesses per segment"}
         if ke and "hbm_bytes_per_segment" in ke:
             al["hbm"] = {"achieved": round(ke["hbm_bytes_per_segment"] * rate / 1e9, 1), "frac": round(ke["hbm_bytes_per_segment"] * rate / 1e9 / HBM_PEAK_GBS, 4)}
         if alone.get("avg_shade_ms", 0) > 0:

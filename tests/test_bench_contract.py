@@ -42,7 +42,8 @@ def test_committed_bench_line_has_the_contract_keys():
         assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0 and 0 < h["frac"] <= 1 and abs(h["frac"] - h["achieved"] / 8000.0) < 1e-3
         assert r["hbm_frac"] == h["frac"] == d["hbm_frac"]
         assert 0 < h[r["kernel"]]["frac"] <= 1 and 0 < h["k_shade"]["frac"] <= 1 and 0 < r["chip_valu_issue"]["frac"] <= 1
-        assert "measured_in" in r["alone"] and 0 < r["alone"]["valu_issue"]["frac"] <= 1 and 0 < r["alone"]["hbm"]["frac"] <= 1 and 0 < r["alone"]["td_busy"]["frac"] <= 1
+        assert "measured_in" in r["alone"] and 0 < r["alone"]["valu_issue"]["frac"] <= 1 and 0 < r["alone"]["hbm"]["frac"] <= 1
+        assert r["alone"]["td_busy"]["frac"] == pk["td_busy_frac_alone"] and 0 < pk["td_busy_frac_alone"] <= 1
         assert r["shade"]["bound"] == "hbm" and 0 < r["shade"]["frac"] <= 1
 
         def no_frac_key(o):
