@@ -3,6 +3,7 @@
 
 Per seed: a small scene, a one-stream or two-stream context, a random path-pool size, then ~14 random calls out of
   pt_render / pt_render_batch / pt_render_batch_async (frame counters running on, or restarting at 1: frag.glsl:924-933 stores instead of adding),
+  bursts of 6-40 one-frame pt_render_batch_async calls (the reference's loop), pt_write_frame of one of the ring's images,
   pt_next_image, pt_reset_frame, pt_read_frame, pt_gather_image of an older image, uploads of ORIGIN / ROTATION / Parameters between batches
   (SAMPLE_RES, MAX_BOUNCES, RAYTRACING, AUTO_FOCUS), pt_set_option(path_slots).
 The model keeps the ring of four FRAME images as numpy arrays and renders every submitted frame with the oracle and the inputs current at its
@@ -76,9 +77,18 @@ def one(seed, verbose=False):
 
     ok = True
     for _ in range(int(rs.randint(8, 20))):
-        op = rs.choice(["render", "batch", "async", "async", "next", "reset", "check", "check_old", "origin", "params", "slots"])
+        op = rs.choice(["render", "batch", "async", "async", "burst", "next", "reset", "check", "check_old", "origin", "params", "slots", "write"])
         if op in ("render", "batch", "async"):
             submit(op, 1 if op == "render" else int(rs.randint(1, 5)))
+        elif op == "burst":                               # the reference's loop: one draw per call, many of them, nothing waited for
+            for _ in range(int(rs.randint(6, 40))):
+                submit("async", 1)
+        elif op == "write":                               # pt_write_frame: one of the ring's images (the model's copy) becomes the current accumulator
+            age = int(rs.randint(0, len(ring)))
+            log.append(f"write_frame(image of age {age})")
+            src = ring[-1 - age].copy()
+            r.write_frame(src); ring[-1][:] = src
+            fc = int(src[0, 0, 3]) + 1 if src[0, 0, 3] >= 1 else 1
         elif op == "next":
             log.append("next_image")
             r.next_image(); ring.append(np.zeros((H, W, 4), np.float32)); ring[:] = ring[-4:]; fc = 1
