@@ -46,7 +46,14 @@ def one(seed, verbose=False):
     scene = oracle.Scene(bufs, wl.sky, wl.textures)
     ring = [np.zeros((H, W, 4), np.float32)]            # ring[-1] = current image, ring[-1 - age] = `age` pt_next_image calls ago
     fc = 1
-    log = []
+
+    class _Log(list):                                   # API_FUZZ_TRACE=<file>: every call is written out BEFORE it is made (a native abort leaves the last one behind)
+        def append(self, x):
+            list.append(self, x)
+            if os.environ.get("API_FUZZ_TRACE"):
+                with open(os.environ["API_FUZZ_TRACE"], "a") as f:
+                    f.write(f"seed {seed}: {x}\n")
+    log = _Log()
 
     def submit(kind, n):
         nonlocal fc
