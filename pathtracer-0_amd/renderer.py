@@ -96,7 +96,8 @@ def lib():
         L.pt_synchronize.argtypes = [vp]
         L.pt_stream_wait.argtypes = [vp]
         L.pt_read_frame.argtypes = [vp, vp]
-        L.pt_write_frame.argtypes = [vp, vp]
+        if hasattr(L, "pt_write_frame"):                      # (absent in A/B builds of earlier rounds loaded through PT_HIP_LIB)
+            L.pt_write_frame.argtypes = [vp, vp]
         L.pt_read_display.argtypes = [vp, ci, ci, vp]
         L.pt_save_png.argtypes = [vp, ci, ci, C.c_char_p]
         L.pt_frame_device.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]

@@ -90,7 +90,7 @@ def one(seed, verbose=False):
         elif op == "burst":                               # the reference's loop: one draw per call, many of them, nothing waited for
             for _ in range(int(rs.randint(6, 40))):
                 submit("async", 1)
-        elif op == "write":                               # pt_write_frame: one of the ring's images (the model's copy) becomes the current accumulator
+        elif op == "write" and hasattr(renderer.lib(), "pt_write_frame"):      # pt_write_frame: one of the ring's images (the model's copy) becomes the current accumulator
             age = int(rs.randint(0, len(ring)))
             log.append(f"write_frame(image of age {age})")
             src = ring[-1 - age].copy()
