@@ -87,10 +87,10 @@ def one(seed, verbose=False):
         op = rs.choice(["render", "batch", "async", "async", "burst", "next", "reset", "check", "check_old", "origin", "params", "slots", "write"])
         if op in ("render", "batch", "async"):
             submit(op, 1 if op == "render" else int(rs.randint(1, 5)))
-        elif op == "burst":                               # the reference's loop: one draw per call, many of them, nothing waited for
+        elif op == "burst" and os.environ.get("API_FUZZ_NO_BURST") != "1":      # the reference's loop: one draw per call, many of them, nothing waited for
             for _ in range(int(rs.randint(6, 40))):
                 submit("async", 1)
-        elif op == "write" and hasattr(renderer.lib(), "pt_write_frame"):      # pt_write_frame: one of the ring's images (the model's copy) becomes the current accumulator
+        elif op == "write" and hasattr(renderer.lib(), "pt_write_frame") and os.environ.get("API_FUZZ_NO_WRITE") != "1":      # pt_write_frame: one of the ring's images (the model's copy) becomes the current accumulator
             age = int(rs.randint(0, len(ring)))
             log.append(f"write_frame(image of age {age})")
             src = ring[-1 - age].copy()
