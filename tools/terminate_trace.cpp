@@ -8,6 +8,7 @@
 #include <cxxabi.h>
 #include <exception>
 #include <typeinfo>
+#include <signal.h>
 #include <unistd.h>
 
 static void handler() {
@@ -27,4 +28,13 @@ static void handler() {
     fflush(stderr);
     abort();
 }
-__attribute__((constructor)) static void install() { std::set_terminate(handler); }
+static void on_abort(int) {      // glibc's heap checks (and MALLOC_CHECK_) end in abort(): the native backtrace of the thread that noticed
+    void* bt[96];
+    const int n = backtrace(bt, 96);
+    const char msg[] = "\n=== SIGABRT: native backtrace ===\n";
+    if (write(2, msg, sizeof msg - 1) < 0) {}
+    backtrace_symbols_fd(bt, n, 2);
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+}
+__attribute__((constructor)) static void install() { std::set_terminate(handler); if (getenv("PT_TRACE_ABORT")) signal(SIGABRT, on_abort); }
