@@ -37,4 +37,4 @@ static void on_abort(int) {      // glibc's heap checks (and MALLOC_CHECK_) end 
     signal(SIGABRT, SIG_DFL);
     raise(SIGABRT);
 }
-__attribute__((constructor)) static void install() { std::set_terminate(handler); if (getenv("PT_TRACE_ABORT")) signal(SIGABRT, on_abort); }
+__attribute__((constructor)) static void install() { std::set_terminate(handler); if (getenv("PT_TRACE_ABORT")) { signal(SIGABRT, on_abort); signal(SIGSEGV, on_abort); } }
