@@ -1566,6 +1566,8 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
+    static const int dbgSched = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0;      // diagnosis only: 1 = no hipEventQuery (a look waits), 2 = one group in flight, waited for at once
+    if (!wait && dbgSched == 1) return 0;
     if (!wait) {
         const hipError_t q = hipEventQuery(g.ev);
         if (q == hipErrorNotReady) return 0;
@@ -1706,8 +1708,9 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         const bool want = kick || !satisfied();
         if (!want) break;
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        const int room = c->draining ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
-        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; continue; }
+        static const int dbgSched2 = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0;
+        const int room = (c->draining || dbgSched2 == 2) ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
+        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; if (dbgSched2 == 2 && (rc = processOldestGroup(c, true, false)) < 0) return rc; continue; }
         if (kick) { kick = false; continue; }                     // two groups are on their way already: the submission rides behind them
         if ((rc = processOldestGroup(c, true, false)) < 0) return rc;
     }
