@@ -34,6 +34,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 using namespace ptd;
@@ -92,6 +94,7 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned long long waveEnd[8192];   // s_memrealtime (100 MHz) at which each wave of the last intersect launch finished
     unsigned long long waveStart[8192]; // ... and started
 #endif
+    unsigned seq;           // the host's number of the group of iterations whose snapshot is being taken (hipMemsetD32Async): copied to the group's pinned stamp BEHIND the snapshot
 };
 // pt_extend_gfx950.s reads these two by their byte offsets
 static_assert(offsetof(Control, exhausted) == 4 && offsetof(Control, qCount) == 96, "Control layout is part of the hand-written kernel");
@@ -920,10 +923,12 @@ struct pt_ctx {
     uint64_t lastSubmitJobs = 0, jobsThisImage = 0, jobsPerImage = 0;      // what the last submission added; jobs submitted for the current / the previous FRAME image
     FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
     // The host polls the device's scheduler words once per GROUP of iterations: a group = its launches + (a scan of the oldest batches) + a copy of Control into
-    // the group's pinned snapshot + an event.  Up to two groups are in flight: the host looks at a snapshot when its event has fired, so the stream always holds
-    // the next group's launches while one runs, and an asynchronous submission never waits for the iterations it started (pump).
-    struct Group { hipEvent_t ev = nullptr; Control* h = nullptr; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; int64_t predicted = 0; };
-    Group grp[2]; int grpHead = 0, grpCount = 0; bool scanInFlight = false; unsigned submitEpoch = 0;
+    // the group's pinned snapshot + a copy of the group's number into the group's pinned STAMP behind it.  Up to two groups are in flight: the host looks at a snapshot when
+    // its stamp has arrived, so the stream always holds the next group's launches while one runs, and an asynchronous submission never waits for the iterations it started
+    // (pump).  No HIP events: a first form recorded an event per group and corrupted the host heap once in ~1000 call sequences of bursts of one-frame submissions
+    // (profiles/r06_f_event_free_looks.txt); a stamp in coherent pinned memory, written by a 4-byte copy the stream orders behind the snapshot, needs nothing from the runtime.
+    struct Group { Control* h = nullptr; volatile unsigned* stamp = nullptr; unsigned seq = 0; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; int64_t predicted = 0; };
+    Group grp[2]; int grpHead = 0, grpCount = 0; bool scanInFlight = false; unsigned submitEpoch = 0, groupSeq = 0;
     int64_t inflightPredicted = 0;  // jobs the groups in flight are expected to hand out (iterations x the rate of the last look): lastNextJob is as old as the oldest of them
     FrameIn* hFrameIn = nullptr; int32_t* hSeeds = nullptr;   // pinned staging (hSeeds: ring like dSeeds)
     // options / stats
@@ -1566,13 +1571,21 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
-    static const int dbgSched = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0;      // diagnosis only: 1 = no hipEventQuery (a look waits), 2 = one group in flight, waited for at once
-    if (!wait && dbgSched == 1) return 0;
-    if (!wait) {
-        const hipError_t q = hipEventQuery(g.ev);
-        if (q == hipErrorNotReady) return 0;
-        if (q != hipSuccess) return fail(PT_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
-    } else if (hipEventSynchronize(g.ev) != hipSuccess) return fail(PT_ERR_HIP, "hipEventSynchronize failed (a kernel of the wavefront stream faulted?)");
+    // has the group's stamp arrived?  (the stream orders the 4-byte copy behind the snapshot's, and pinned coherent memory needs no synchronisation to be read)
+    auto landed = [&]() { return *g.stamp == g.seq; };
+    if (!landed()) {
+        if (!wait) return 0;
+        for (int spin = 0; spin < 4000 && !landed(); spin++) __builtin_ia32_pause();
+        for (uint64_t n = 0; !landed(); n++) {
+            std::this_thread::sleep_for(std::chrono::microseconds(n < 100 ? 20 : 100));
+            if ((n & 1023) == 1023) {                              // every ~0.1 s: is the stream still working?  an idle stream without the stamp is a lost launch, an error a fault
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q != hipSuccess && q != hipErrorNotReady) return fail(PT_ERR_HIP, std::string("the wavefront stream failed: ") + hipGetErrorString(q));
+                if (q == hipSuccess && !landed()) return fail(PT_ERR_HIP, "the wavefront stream is idle but a group's snapshot never arrived (internal error)");
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     c->grpCount--;
     if (g.nScan) c->scanInFlight = false;
     c->inflightPredicted = std::max<int64_t>(0, c->inflightPredicted - g.predicted);
@@ -1696,8 +1709,11 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
                 g.nScan = ends.n; g.scanF0 = c->pending.front().f0; c->scanInFlight = true;
             }
         }
+        if (++c->groupSeq == 0) c->groupSeq = 1;                   // (0 = "nothing has arrived")
+        g.seq = c->groupSeq; *g.stamp = 0;
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&c->dCtl->seq, (int)g.seq, 1, s));
         HIP_TRY(hipMemcpyAsync(g.h, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(g.ev, s));
+        HIP_TRY(hipMemcpyAsync((void*)g.stamp, &c->dCtl->seq, 4, hipMemcpyDeviceToHost, s));      // behind the snapshot in stream order: when it has arrived, so has the snapshot
         c->grpHead = (c->grpHead + 1) % 2; c->grpCount++;
         return 0;
     };
@@ -1708,9 +1724,8 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         const bool want = kick || !satisfied();
         if (!want) break;
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        static const int dbgSched2 = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0;
-        const int room = (c->draining || dbgSched2 == 2) ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
-        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; if (dbgSched2 == 2 && (rc = processOldestGroup(c, true, false)) < 0) return rc; continue; }
+        const int room = c->draining ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
+        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; continue; }
         if (kick) { kick = false; continue; }                     // two groups are on their way already: the submission rides behind them
         if ((rc = processOldestGroup(c, true, false)) < 0) return rc;
     }
@@ -1907,7 +1922,11 @@ int initContext(pt_ctx* c, int width, int height, int shard_rank, int shard_coun
     HIP_TRY(hipMalloc((void**)&c->dFc, sizeof(FrameConst)));
     HIP_TRY(hipMalloc((void**)&c->dCtl, sizeof(Control)));
     HIP_TRY(hipMemset(c->dCtl, 0, sizeof(Control)));
-    for (auto& g : c->grp) { HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(Control), hipHostMallocDefault)); HIP_TRY(hipEventCreateWithFlags(&g.ev, hipEventDisableTiming)); }
+    for (auto& g : c->grp) {
+        HIP_TRY(hipHostMalloc((void**)&g.h, sizeof(Control), hipHostMallocCoherent));
+        HIP_TRY(hipHostMalloc((void**)&g.stamp, 64, hipHostMallocCoherent));
+        *g.stamp = 0;
+    }
     HIP_TRY(hipHostMalloc((void**)&c->hFrameIn, sizeof(FrameIn), hipHostMallocDefault));
     return 0;
 }
@@ -2009,7 +2028,7 @@ int pt_destroy(pt_ctx* c) {
     void* ptrs[] = {c->dNiTable, c->st.J, c->dNodes80, c->dTexels, c->dTexTable, c->dTriObj, c->dNodes, c->dTris, c->dShade, c->dRoots, c->dEllip, c->dMats, c->dSky, c->dPixList, c->dPixXY, c->dAllMaps, c->dImage[0], c->dImage[1], c->dImage[2], c->dImage[3], c->st.G0, c->st.G1, c->st.G2,
                     c->st.G3, c->st.G4, c->st.G5, c->st.S0, c->st.H, c->st.HX, c->dQueue[0], c->dQueue[1], c->dColbuf, c->dSeeds, c->dFrameIn, c->dFc, c->dCtl, c->dDisplay};
     for (void* p : ptrs) if (p) hipFree(p);
-    for (auto& g : c->grp) { if (g.h) hipHostFree(g.h); if (g.ev) hipEventDestroy(g.ev); }
+    for (auto& g : c->grp) { if (g.h) hipHostFree(g.h); if (g.stamp) hipHostFree((void*)g.stamp); }
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
     if (c->hSeeds) hipHostFree(c->hSeeds);
     for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
