@@ -1569,6 +1569,7 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
 // rows are still owned by unretired batches.
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
+static int schedDebug() { static const int v = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0; return v; }      // diagnosis only (scripts/fuzz_bisect.sh)
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
     // has the group's stamp arrived?  (the stream orders the 4-byte copy behind the snapshot's, and pinned coherent memory needs no synchronisation to be read)
@@ -1654,7 +1655,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     // 24 iterations, in the tail 8; each look shrinks the launch grids to the live count.
     auto launchGroup = [&](bool kick) -> int {
         int CHECK = c->draining ? 8 : 24;
-        if (kick && c->lastDelta == 0) CHECK = 4;                  // the first looks of a stream fed in small submissions come early: the pool grows with the backlog they report
+        if (kick && c->lastDelta == 0 && !(schedDebug() & 4)) CHECK = 4;                  // the first looks of a stream fed in small submissions come early: the pool grows with the backlog they report
         const int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));      // jobs handed out per iteration at the last look
         if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
             const int64_t backlog = std::max<int64_t>(0, (int64_t)c->streamJobs - (int64_t)c->lastNextJob - c->inflightPredicted);      // as of the last look, less what the groups in flight take
@@ -1700,7 +1701,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (!c->scanInFlight) {
             ScanEnds ends{};
             for (const auto& e : c->pending) {
-                if (ends.n == 8 || c->lastNextJob < e.jobEnd) break;
+                if (ends.n == ((schedDebug() & 1) ? 1 : 8) || c->lastNextJob < e.jobEnd) break;
                 ends.f[ends.n++] = e.f0 + (unsigned)e.nFrames;
             }
             if (ends.n) {
@@ -1724,8 +1725,8 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         const bool want = kick || !satisfied();
         if (!want) break;
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        const int room = c->draining ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
-        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; continue; }
+        const int room = (c->draining || (schedDebug() & 2)) ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
+        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; if ((schedDebug() & 2) && (rc = processOldestGroup(c, true, false)) < 0) return rc; continue; }
         if (kick) { kick = false; continue; }                     // two groups are on their way already: the submission rides behind them
         if ((rc = processOldestGroup(c, true, false)) < 0) return rc;
     }
