@@ -2,9 +2,12 @@
 // every block gets a 32-byte header (magic, size, caller) and a 16-byte tail canary; free() / realloc() verify both and, when one is smashed, print the
 // block's size and WHO ALLOCATED IT (return address + library), then abort.  Test / diagnosis infrastructure only.
 //   g++ -O1 -fPIC -shared -o build/canary_malloc.so tools/canary_malloc.cpp -ldl ;  LD_PRELOAD=build/canary_malloc.so python3 ...
+#ifndef _GNU_SOURCE
 #define _GNU_SOURCE
+#endif
 #include <dlfcn.h>
 #include <execinfo.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -59,6 +62,21 @@ void report(const char* what, Hdr* h, void* user) {
     void* bt[48]; int m = backtrace(bt, 48); backtrace_symbols_fd(bt, m, 2);
     abort();
 }
+// freed blocks of up to 64 KB are filled with 0xDD and parked; when a parked block leaves the ring its fill is verified: a write AFTER free names the block it hit
+const int PARK = 8192;
+void* parked[PARK]; int park_at; pthread_mutex_t park_lock = PTHREAD_MUTEX_INITIALIZER;
+void verify_parked(void* user) {
+    Hdr* h = (Hdr*)((char*)user - sizeof(Hdr));
+    unsigned char* b = (unsigned char*)user;
+    for (size_t k = 0; k < h->size; k++)
+        if (b[k] != 0xDD) {
+            char msg[256]; int n = snprintf(msg, sizeof msg, "\n=== canary_malloc: byte %zu of a FREED block was written (now %02x)", k, b[k]);
+            if (write(2, msg, n) < 0) {}
+            h->magic = MAGIC; report("WRITE AFTER FREE", h, user);
+        }
+    uint64_t t[2]; memcpy(t, (char*)user + h->size, 16);
+    if (t[0] != TAIL || t[1] != TAIL) { h->magic = MAGIC; report("WRITE PAST THE END (after free)", h, user); }
+}
 Hdr* check(void* p) {      // null: not one of ours
     Hdr* h = (Hdr*)((char*)p - sizeof(Hdr));
     if (h->magic != MAGIC) return nullptr;
@@ -77,8 +95,16 @@ void free(void* p) {
     Hdr* h = check(p);
     if (!h) { if (real_free) real_free(p); return; }
     h->magic = 0;
-    void* raw = h->raw;
-    real_free(raw);
+    if (h->size <= (64u << 10)) {
+        memset(p, 0xDD, h->size);
+        pthread_mutex_lock(&park_lock);
+        void* old = parked[park_at]; parked[park_at] = p; park_at = (park_at + 1) % PARK;
+        pthread_mutex_unlock(&park_lock);
+        if (!old) return;
+        verify_parked(old);
+        p = old; h = (Hdr*)((char*)p - sizeof(Hdr));
+    }
+    real_free(h->raw);
 }
 void* realloc(void* p, size_t n) {
     if (!p) return make(n, 16, __builtin_return_address(0));
