@@ -799,6 +799,7 @@ __global__ void __launch_bounds__(64) k_debug_heatmap(DevScene sc, Batch b, cons
 // Which of the (up to 8) oldest batches that have not been accumulated yet does a live slot still work on?  ends.f[k] = first stream frame BEHIND the k-th of
 // them (ascending): a live slot on frame f keeps the first batch with f < ends.f[k] busy.  One pass over the flags per host poll.
 struct ScanEnds { unsigned f[8]; int n; };
+__global__ void k_clear_busy(Control* ctl) { ctl->busy[threadIdx.x & 7] = 0u; }      // diagnosis (PT_SCHED_DEBUG & 16)
 __global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, ScanEnds ends, Control* ctl) {
     unsigned i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= (unsigned)nSlots) return;
@@ -1571,7 +1572,7 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
 static int schedDebug() { static const int v = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0; return v; }      // diagnosis only (scripts/fuzz_bisect.sh)
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
-    pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
+    pt_ctx::Group& g = c->grp[(schedDebug() & 32) ? 0 : (c->grpHead + 2 - c->grpCount) % 2];
     // has the group's stamp arrived?  (the stream orders the 4-byte copy behind the snapshot's, and pinned coherent memory needs no synchronisation to be read)
     auto landed = [&]() { return *g.stamp == g.seq; };
     if (!landed()) {
@@ -1694,7 +1695,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (part) HIP_TRY(hipStreamWaitEvent(s, c->evShade, 0));
         HIP_TRY(hipGetLastError());                                // a failed launch surfaces here, not as "did not drain"
         if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
-        pt_ctx::Group& g = c->grp[c->grpHead];
+        pt_ctx::Group& g = c->grp[(schedDebug() & 32) ? 0 : c->grpHead];
         g.check = CHECK; g.iterEnd = c->iter; g.epoch = c->submitEpoch; g.nScan = 0;
         g.predicted = c->lastDelta > 0 ? (int64_t)CHECK * perIter : 0; c->inflightPredicted += g.predicted;
         // have the oldest batches been handed out completely (as of the last look)?  then see which of them are still in flight (one scan in flight at a time)
@@ -1705,7 +1706,8 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
                 ends.f[ends.n++] = e.f0 + (unsigned)e.nFrames;
             }
             if (ends.n) {
-                HIP_TRY(hipMemsetAsync(c->dCtl->busy, 0, sizeof(c->dCtl->busy), s));
+                if (schedDebug() & 16) hipLaunchKernelGGL(k_clear_busy, dim3(1), dim3(8), 0, s, c->dCtl);
+                else HIP_TRY(hipMemsetAsync(c->dCtl->busy, 0, sizeof(c->dCtl->busy), s));
                 hipLaunchKernelGGL(k_scan_inflight, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, c->st, N, ends, c->dCtl);
                 g.nScan = ends.n; g.scanF0 = c->pending.front().f0; c->scanInFlight = true;
             }
@@ -1715,7 +1717,9 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&c->dCtl->seq, (int)g.seq, 1, s));
         HIP_TRY(hipMemcpyAsync(g.h, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync((void*)g.stamp, &c->dCtl->seq, 4, hipMemcpyDeviceToHost, s));      // behind the snapshot in stream order: when it has arrived, so has the snapshot
-        c->grpHead = (c->grpHead + 1) % 2; c->grpCount++;
+        if (schedDebug() & 8) HIP_TRY(hipStreamSynchronize(s));
+        if (!(schedDebug() & 32)) c->grpHead = (c->grpHead + 1) % 2;
+        c->grpCount++;
         return 0;
     };
     int rc;
