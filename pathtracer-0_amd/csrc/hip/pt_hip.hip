@@ -94,7 +94,6 @@ struct Control {            // device-resident scheduler words shared by the who
     unsigned long long waveEnd[8192];   // s_memrealtime (100 MHz) at which each wave of the last intersect launch finished
     unsigned long long waveStart[8192]; // ... and started
 #endif
-    unsigned seq;           // the host's number of the group of iterations whose snapshot is being taken (hipMemsetD32Async): copied to the group's pinned stamp BEHIND the snapshot
 };
 // pt_extend_gfx950.s reads these two by their byte offsets
 static_assert(offsetof(Control, exhausted) == 4 && offsetof(Control, qCount) == 96, "Control layout is part of the hand-written kernel");
@@ -799,7 +798,17 @@ __global__ void __launch_bounds__(64) k_debug_heatmap(DevScene sc, Batch b, cons
 // Which of the (up to 8) oldest batches that have not been accumulated yet does a live slot still work on?  ends.f[k] = first stream frame BEHIND the k-th of
 // them (ascending): a live slot on frame f keeps the first batch with f < ends.f[k] busy.  One pass over the flags per host poll.
 struct ScanEnds { unsigned f[8]; int n; };
-__global__ void k_clear_busy(Control* ctl) { ctl->busy[threadIdx.x & 7] = 0u; }      // diagnosis (PT_SCHED_DEBUG & 16)
+// The host's look at the scheduler words: ONE wave copies Control into the group's snapshot in pinned, coherent host memory and, behind a system-scope fence, writes
+// the group's number into the group's stamp.  A kernel, not hipMemcpyAsync: the runtime's device-to-host copy into pinned memory, left without a hipStreamSynchronize
+// behind it, released one of its own objects twice (a write into freed memory inside libamdhip64, found by tools/canary_malloc.cpp: profiles/r06_f_looks_without_the_copy_engine.txt).
+__global__ void __launch_bounds__(64) k_snapshot(const Control* ctl, Control* snap, volatile unsigned* stamp, unsigned seq) {
+    const unsigned* s = reinterpret_cast<const unsigned*>(ctl);
+    unsigned* d = reinterpret_cast<unsigned*>(snap);
+    for (unsigned i = threadIdx.x; i < sizeof(Control) / 4; i += 64) d[i] = s[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *stamp = seq; __threadfence_system(); }
+}
 __global__ void __launch_bounds__(BLOCK) k_scan_inflight(State st, int nSlots, ScanEnds ends, Control* ctl) {
     unsigned i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= (unsigned)nSlots) return;
@@ -926,8 +935,8 @@ struct pt_ctx {
     // The host polls the device's scheduler words once per GROUP of iterations: a group = its launches + (a scan of the oldest batches) + a copy of Control into
     // the group's pinned snapshot + a copy of the group's number into the group's pinned STAMP behind it.  Up to two groups are in flight: the host looks at a snapshot when
     // its stamp has arrived, so the stream always holds the next group's launches while one runs, and an asynchronous submission never waits for the iterations it started
-    // (pump).  No HIP events: a first form recorded an event per group and corrupted the host heap once in ~1000 call sequences of bursts of one-frame submissions
-    // (profiles/r06_f_event_free_looks.txt); a stamp in coherent pinned memory, written by a 4-byte copy the stream orders behind the snapshot, needs nothing from the runtime.
+    // (pump).  Snapshot and stamp are written by a KERNEL (k_snapshot) into coherent pinned memory and read by the host without any runtime call: the runtime's own
+    // device-to-host copy, with events or stamps behind it instead of a hipStreamSynchronize, corrupted the host heap (profiles/r06_f_looks_without_the_copy_engine.txt).
     struct Group { Control* h = nullptr; volatile unsigned* stamp = nullptr; unsigned seq = 0; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; int64_t predicted = 0; };
     Group grp[2]; int grpHead = 0, grpCount = 0; bool scanInFlight = false; unsigned submitEpoch = 0, groupSeq = 0;
     int64_t inflightPredicted = 0;  // jobs the groups in flight are expected to hand out (iterations x the rate of the last look): lastNextJob is as old as the oldest of them
@@ -1573,7 +1582,7 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 static int schedDebug() { static const int v = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0; return v; }      // diagnosis only (scripts/fuzz_bisect.sh)
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(schedDebug() & 32) ? 0 : (c->grpHead + 2 - c->grpCount) % 2];
-    // has the group's stamp arrived?  (the stream orders the 4-byte copy behind the snapshot's, and pinned coherent memory needs no synchronisation to be read)
+    // has the group's stamp arrived?  (k_snapshot writes it behind a system-scope fence after the snapshot; pinned coherent memory needs no synchronisation to be read)
     auto landed = [&]() { return *g.stamp == g.seq; };
     if (!landed()) {
         if (!wait) return 0;
@@ -1706,17 +1715,15 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
                 ends.f[ends.n++] = e.f0 + (unsigned)e.nFrames;
             }
             if (ends.n) {
-                if (schedDebug() & 16) hipLaunchKernelGGL(k_clear_busy, dim3(1), dim3(8), 0, s, c->dCtl);
-                else HIP_TRY(hipMemsetAsync(c->dCtl->busy, 0, sizeof(c->dCtl->busy), s));
+                HIP_TRY(hipMemsetAsync(c->dCtl->busy, 0, sizeof(c->dCtl->busy), s));
                 hipLaunchKernelGGL(k_scan_inflight, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, c->st, N, ends, c->dCtl);
                 g.nScan = ends.n; g.scanF0 = c->pending.front().f0; c->scanInFlight = true;
             }
         }
         if (++c->groupSeq == 0) c->groupSeq = 1;                   // (0 = "nothing has arrived")
         g.seq = c->groupSeq; *g.stamp = 0;
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&c->dCtl->seq, (int)g.seq, 1, s));
-        HIP_TRY(hipMemcpyAsync(g.h, c->dCtl, sizeof(Control), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync((void*)g.stamp, &c->dCtl->seq, 4, hipMemcpyDeviceToHost, s));      // behind the snapshot in stream order: when it has arrived, so has the snapshot
+        hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, s, c->dCtl, g.h, g.stamp, g.seq);
+        HIP_TRY(hipGetLastError());
         if (schedDebug() & 8) HIP_TRY(hipStreamSynchronize(s));
         if (!(schedDebug() & 32)) c->grpHead = (c->grpHead + 1) % 2;
         c->grpCount++;
