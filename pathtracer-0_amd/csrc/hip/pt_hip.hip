@@ -1708,7 +1708,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         g.check = CHECK; g.iterEnd = c->iter; g.epoch = c->submitEpoch; g.nScan = 0;
         g.predicted = c->lastDelta > 0 ? (int64_t)CHECK * perIter : 0; c->inflightPredicted += g.predicted;
         // have the oldest batches been handed out completely (as of the last look)?  then see which of them are still in flight (one scan in flight at a time)
-        if (!c->scanInFlight) {
+        if (!c->scanInFlight && !(schedDebug() & 128)) {
             ScanEnds ends{};
             for (const auto& e : c->pending) {
                 if (ends.n == ((schedDebug() & 1) ? 1 : 8) || c->lastNextJob < e.jobEnd) break;
@@ -1730,6 +1730,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         return 0;
     };
     int rc;
+    if (schedDebug() & 256) (void)hipStreamQuery(s);
     bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going: about as many iterations as consume what it added
     while (c->grpCount > 0 && (rc = processOldestGroup(c, false, false)) != 0) if (rc < 0) return rc;      // whatever has finished since the last call
     for (;;) {
@@ -1857,6 +1858,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
         unsigned r0 = f0 % (unsigned)c->ringFrames, n0 = std::min<unsigned>((unsigned)nFrames, (unsigned)c->ringFrames - r0);
         HIP_TRY(hipMemcpyAsync(c->dSeeds + r0, c->hSeeds + r0, (size_t)n0 * 4, hipMemcpyHostToDevice, s));
         if (n0 < (unsigned)nFrames) HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)(nFrames - n0) * 4, hipMemcpyHostToDevice, s));
+        if (schedDebug() & 64) HIP_TRY(hipStreamSynchronize(s));
     }
     hipLaunchKernelGGL(k_submit, dim3(1), dim3(1), 0, s, c->dCtl, (unsigned)nJobs64, join ? (grown ? 2 : 0) : 1, (unsigned)c->poolActive);
     const Batch b = streamBatch(c);
