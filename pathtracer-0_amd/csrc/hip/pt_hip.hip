@@ -1530,7 +1530,7 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
 Batch streamBatch(const pt_ctx* c) {
     Batch b;
     b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount;
-    b.ringFrames = (unsigned)c->ringFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
+    b.ringFrames = (unsigned)c->ringFrames; b.seeds = (schedDebug() & 512) ? c->hSeeds : c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
     if (c->nLocal >= 2) {                                     // ceil(2^(31+l)/d), exact for every job < 2^31
         unsigned d = (unsigned)c->nLocal; int l = 0;
         while ((1ull << l) < d) l++;
@@ -1854,7 +1854,7 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     // ---- append
     const unsigned f0 = c->streamFrames;
     for (int f = 0; f < nFrames; f++) c->hSeeds[(f0 + (unsigned)f) % (unsigned)c->ringFrames] = seeds[f];
-    {
+    if (!(schedDebug() & 512)) {
         unsigned r0 = f0 % (unsigned)c->ringFrames, n0 = std::min<unsigned>((unsigned)nFrames, (unsigned)c->ringFrames - r0);
         HIP_TRY(hipMemcpyAsync(c->dSeeds + r0, c->hSeeds + r0, (size_t)n0 * 4, hipMemcpyHostToDevice, s));
         if (n0 < (unsigned)nFrames) HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)(nFrames - n0) * 4, hipMemcpyHostToDevice, s));
