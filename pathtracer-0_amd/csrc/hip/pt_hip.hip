@@ -44,6 +44,7 @@ namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
+static int schedDebug() { static const int v = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0; return v; }      // diagnosis only (scripts/fuzz_bisect.sh)
 #define HIP_TRY(x)                                                                                         \
     do {                                                                                                   \
         hipError_t e_ = (x);                                                                               \
@@ -1579,7 +1580,6 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
 // rows are still owned by unretired batches.
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
-static int schedDebug() { static const int v = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0; return v; }      // diagnosis only (scripts/fuzz_bisect.sh)
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(schedDebug() & 32) ? 0 : (c->grpHead + 2 - c->grpCount) % 2];
     // has the group's stamp arrived?  (k_snapshot writes it behind a system-scope fence after the snapshot; pinned coherent memory needs no synchronisation to be read)
