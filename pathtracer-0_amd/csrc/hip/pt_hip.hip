@@ -44,7 +44,6 @@ namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
-static int schedDebug() { static const int v = std::getenv("PT_SCHED_DEBUG") ? std::atoi(std::getenv("PT_SCHED_DEBUG")) : 0; return v; }      // diagnosis only (scripts/fuzz_bisect.sh)
 #define HIP_TRY(x)                                                                                         \
     do {                                                                                                   \
         hipError_t e_ = (x);                                                                               \
@@ -1531,7 +1530,7 @@ void launchExtendPersist(pt_ctx* c, const PoolRun& pr) {
 Batch streamBatch(const pt_ctx* c) {
     Batch b;
     b.W = c->W; b.H = c->H; b.nLocal = c->nLocal; b.nSlots = c->nSlotsImg; b.shardCount = c->shardCount;
-    b.ringFrames = (unsigned)c->ringFrames; b.seeds = (schedDebug() & 512) ? c->hSeeds : c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
+    b.ringFrames = (unsigned)c->ringFrames; b.seeds = c->dSeeds; b.pixList = c->dPixList; b.pixXY = c->dPixXY; b.colbuf = c->dColbuf;
     if (c->nLocal >= 2) {                                     // ceil(2^(31+l)/d), exact for every job < 2^31
         unsigned d = (unsigned)c->nLocal; int l = 0;
         while ((1ull << l) < d) l++;
@@ -1580,8 +1579,16 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
 // rows are still owned by unretired batches.
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
+// A stream that is never synchronised must still be LOOKED AT through the runtime: with launches queued for seconds and no hipStreamSynchronize / hipStreamQuery on the
+// stream, the HIP runtime (7.0.2 as bundled with torch) wrote into a freed 920-byte object of its own — a reference count released twice — about once in a thousand
+// sequences of one-frame submissions, and the host heap went with it (glibc aborts, std::bad_variant_access out of libamdhip64).  hipStreamQuery makes the runtime
+// retire the commands that have completed; with one per look and per call the same 4000 sequences are clean under a checking allocator
+// (tools/canary_malloc.cpp, profiles/r06_f_runtime_write_after_free.txt).  The round-5 scheduler synchronised the stream at every look and never met this.
+inline void reapStream(pt_ctx* c) { (void)hipStreamQuery(c->stream); }
+
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
-    pt_ctx::Group& g = c->grp[(schedDebug() & 32) ? 0 : (c->grpHead + 2 - c->grpCount) % 2];
+    pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
+    reapStream(c);
     // has the group's stamp arrived?  (k_snapshot writes it behind a system-scope fence after the snapshot; pinned coherent memory needs no synchronisation to be read)
     auto landed = [&]() { return *g.stamp == g.seq; };
     if (!landed()) {
@@ -1665,7 +1672,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     // 24 iterations, in the tail 8; each look shrinks the launch grids to the live count.
     auto launchGroup = [&](bool kick) -> int {
         int CHECK = c->draining ? 8 : 24;
-        if (kick && c->lastDelta == 0 && !(schedDebug() & 4)) CHECK = 4;                  // the first looks of a stream fed in small submissions come early: the pool grows with the backlog they report
+        if (kick && c->lastDelta == 0) CHECK = 4;                  // the first looks of a stream fed in small submissions come early: the pool grows with the backlog they report
         const int64_t perIter = std::max<int64_t>(1, (int64_t)c->lastDelta / std::max(1, c->lastCheck));      // jobs handed out per iteration at the last look
         if (until == PUMP_ISSUED && c->lastDelta > 0) {           // approach the end of the job supply without running into it
             const int64_t backlog = std::max<int64_t>(0, (int64_t)c->streamJobs - (int64_t)c->lastNextJob - c->inflightPredicted);      // as of the last look, less what the groups in flight take
@@ -1704,14 +1711,14 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         if (part) HIP_TRY(hipStreamWaitEvent(s, c->evShade, 0));
         HIP_TRY(hipGetLastError());                                // a failed launch surfaces here, not as "did not drain"
         if (!c->asmError.empty()) { const std::string m = c->asmError; c->asmError.clear(); return fail(PT_ERR_HIP, m); }
-        pt_ctx::Group& g = c->grp[(schedDebug() & 32) ? 0 : c->grpHead];
+        pt_ctx::Group& g = c->grp[c->grpHead];
         g.check = CHECK; g.iterEnd = c->iter; g.epoch = c->submitEpoch; g.nScan = 0;
         g.predicted = c->lastDelta > 0 ? (int64_t)CHECK * perIter : 0; c->inflightPredicted += g.predicted;
         // have the oldest batches been handed out completely (as of the last look)?  then see which of them are still in flight (one scan in flight at a time)
-        if (!c->scanInFlight && !(schedDebug() & 128)) {
+        if (!c->scanInFlight) {
             ScanEnds ends{};
             for (const auto& e : c->pending) {
-                if (ends.n == ((schedDebug() & 1) ? 1 : 8) || c->lastNextJob < e.jobEnd) break;
+                if (ends.n == 8 || c->lastNextJob < e.jobEnd) break;
                 ends.f[ends.n++] = e.f0 + (unsigned)e.nFrames;
             }
             if (ends.n) {
@@ -1724,21 +1731,19 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         g.seq = c->groupSeq; *g.stamp = 0;
         hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(64), 0, s, c->dCtl, g.h, g.stamp, g.seq);
         HIP_TRY(hipGetLastError());
-        if (schedDebug() & 8) HIP_TRY(hipStreamSynchronize(s));
-        if (!(schedDebug() & 32)) c->grpHead = (c->grpHead + 1) % 2;
-        c->grpCount++;
+        c->grpHead = (c->grpHead + 1) % 2; c->grpCount++;
         return 0;
     };
     int rc;
-    if (schedDebug() & 256) (void)hipStreamQuery(s);
+    reapStream(c);
     bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going: about as many iterations as consume what it added
     while (c->grpCount > 0 && (rc = processOldestGroup(c, false, false)) != 0) if (rc < 0) return rc;      // whatever has finished since the last call
     for (;;) {
         const bool want = kick || !satisfied();
         if (!want) break;
         if (iters > maxIters) return fail(PT_ERR_HIP, "wavefront scheduler did not drain (internal error)");
-        const int room = (c->draining || (schedDebug() & 2)) ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
-        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; if ((schedDebug() & 2) && (rc = processOldestGroup(c, true, false)) < 0) return rc; continue; }
+        const int room = c->draining ? 1 : 2;                     // the tail is run look by look: every look shrinks the grids
+        if (c->grpCount < room) { if ((rc = launchGroup(kick))) return rc; kick = false; continue; }
         if (kick) { kick = false; continue; }                     // two groups are on their way already: the submission rides behind them
         if ((rc = processOldestGroup(c, true, false)) < 0) return rc;
     }
@@ -1854,11 +1859,10 @@ int submitBatch(pt_ctx* c, int firstFrame, int nFrames, const int32_t* seeds, bo
     // ---- append
     const unsigned f0 = c->streamFrames;
     for (int f = 0; f < nFrames; f++) c->hSeeds[(f0 + (unsigned)f) % (unsigned)c->ringFrames] = seeds[f];
-    if (!(schedDebug() & 512)) {
+    {
         unsigned r0 = f0 % (unsigned)c->ringFrames, n0 = std::min<unsigned>((unsigned)nFrames, (unsigned)c->ringFrames - r0);
         HIP_TRY(hipMemcpyAsync(c->dSeeds + r0, c->hSeeds + r0, (size_t)n0 * 4, hipMemcpyHostToDevice, s));
         if (n0 < (unsigned)nFrames) HIP_TRY(hipMemcpyAsync(c->dSeeds, c->hSeeds, (size_t)(nFrames - n0) * 4, hipMemcpyHostToDevice, s));
-        if (schedDebug() & 64) HIP_TRY(hipStreamSynchronize(s));
     }
     hipLaunchKernelGGL(k_submit, dim3(1), dim3(1), 0, s, c->dCtl, (unsigned)nJobs64, join ? (grown ? 2 : 0) : 1, (unsigned)c->poolActive);
     const Batch b = streamBatch(c);
