@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <chrono>
@@ -1919,8 +1920,23 @@ extern "C" {
 const char* pt_last_error(void) { return g_err.c_str(); }
 
 namespace {
+// The streams of destroyed contexts are kept for later contexts of the process instead of being destroyed: hipStreamDestroy right behind a long asynchronous run
+// (hundreds of commands retired moments ago) is where the HIP runtime wrote into a freed object of its own (see reapStream).  Streams are few and small.
+std::mutex g_streamPoolLock;
+std::vector<std::pair<int, hipStream_t>> g_streamPool;
+int takeStream(int device, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_streamPoolLock);
+        for (size_t k = 0; k < g_streamPool.size(); k++)
+            if (g_streamPool[k].first == device) { *out = g_streamPool[k].second; g_streamPool.erase(g_streamPool.begin() + (long)k); return 0; }
+    }
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return 0;
+}
+void giveStream(int device, hipStream_t s) { std::lock_guard<std::mutex> lk(g_streamPoolLock); g_streamPool.emplace_back(device, s); }
+
 int initContext(pt_ctx* c, int width, int height, int shard_rank, int shard_count) {
-    HIP_TRY(hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking));
+    HIP_TRY(takeStream(c->device, &c->ownStream));
     c->stream = c->ownStream;
     shardPixels(width, height, shard_rank, shard_count, c->pixList);
     c->nLocal = (int)c->pixList.size();
@@ -2053,7 +2069,7 @@ int pt_destroy(pt_ctx* c) {
     if (c->sExt) hipStreamDestroy(c->sExt);
     if (c->sShade) hipStreamDestroy(c->sShade);
     for (hipEvent_t e : {c->evExt, c->evShade, c->evHost}) if (e) hipEventDestroy(e);
-    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    if (c->ownStream) { hipStreamSynchronize(c->ownStream); giveStream(c->device, c->ownStream); }
     delete c;
     return PT_OK;
 }
