@@ -1936,7 +1936,7 @@ int takeStream(int device, hipStream_t* out) {
 void giveStream(int device, hipStream_t s) { std::lock_guard<std::mutex> lk(g_streamPoolLock); g_streamPool.emplace_back(device, s); }
 
 int initContext(pt_ctx* c, int width, int height, int shard_rank, int shard_count) {
-    HIP_TRY(takeStream(c->device, &c->ownStream));
+    { const int rc = takeStream(c->device, &c->ownStream); if (rc) return rc; }
     c->stream = c->ownStream;
     shardPixels(width, height, shard_rank, shard_count, c->pixList);
     c->nLocal = (int)c->pixList.size();
