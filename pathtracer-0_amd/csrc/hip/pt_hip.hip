@@ -1585,7 +1585,7 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // sequences of one-frame submissions, and the host heap went with it (glibc aborts, std::bad_variant_access out of libamdhip64).  hipStreamQuery makes the runtime
 // retire the commands that have completed; with one per look and per call the same 4000 sequences are clean under a checking allocator
 // (tools/canary_malloc.cpp, profiles/r06_f_runtime_write_after_free.txt).  The round-5 scheduler synchronised the stream at every look and never met this.
-inline void reapStream(pt_ctx* c) { (void)hipStreamQuery(c->stream); }
+inline void reapStream(pt_ctx* c) { static const bool off = std::getenv("PT_NO_REAP") != nullptr; if (!off) (void)hipStreamQuery(c->stream); }
 
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
