@@ -1552,13 +1552,34 @@ int retireFront(pt_ctx* c) {
     return 0;
 }
 
+// The streams of destroyed contexts are kept for later contexts of the process instead of being destroyed.  hipStreamDestroy right behind a long asynchronous run —
+// hundreds of commands retired moments ago, the stream synchronised, the device synchronised — is where the HIP runtime (7.0.2 as bundled with torch) went on to
+// decrement a counter inside the freed 920-byte stream object: a write after free that took the host heap with it about once in a thousand call sequences (glibc
+// aborts, a std::bad_variant_access out of libamdhip64).  Found with a checking allocator (tools/canary_malloc.cpp), bisected to the scheduler that no longer
+// synchronises the stream at every look, cured by never destroying a stream: 2500 sequences clean (profiles/r06_f_runtime_write_after_free.txt).  Streams are few
+// and small.  key: the device, or (device + 1) * 100 + e (+ 50) for the CU-masked pair of the partition experiment.
+std::mutex g_streamPoolLock;
+std::vector<std::pair<int, hipStream_t>> g_streamPool;
+bool pooledStream(int key, hipStream_t* out) {
+    std::lock_guard<std::mutex> lk(g_streamPoolLock);
+    for (size_t k = 0; k < g_streamPool.size(); k++)
+        if (g_streamPool[k].first == key) { *out = g_streamPool[k].second; g_streamPool.erase(g_streamPool.begin() + (long)k); return true; }
+    return false;
+}
+int takeStream(int device, hipStream_t* out) {
+    if (pooledStream(device, out)) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return 0;
+}
+void giveStream(int device, hipStream_t s) { std::lock_guard<std::mutex> lk(g_streamPoolLock); g_streamPool.emplace_back(device, s); }
+
 // CU-masked streams of the spatial partition.  Bit k of a mask is CU k in the driver's order; whether consecutive bits walk the CUs of one XCD or the XCDs round-robin,
 // the pattern ((k / 8) + (k % 8)) % 8 < e puts 4 e of every XCD's 32 CUs on the intersect side.
 int ensurePartition(pt_ctx* c) {
     if (c->cuPartition == c->cuPartitionBuilt) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->sExt) { hipStreamSynchronize(c->sExt); hipStreamDestroy(c->sExt); c->sExt = nullptr; }
-    if (c->sShade) { hipStreamSynchronize(c->sShade); hipStreamDestroy(c->sShade); c->sShade = nullptr; }
+    if (c->sExt) { hipStreamSynchronize(c->sExt); giveStream((c->device + 1) * 100 + c->cuPartitionBuilt, c->sExt); c->sExt = nullptr; }
+    if (c->sShade) { hipStreamSynchronize(c->sShade); giveStream((c->device + 1) * 100 + 50 + c->cuPartitionBuilt, c->sShade); c->sShade = nullptr; }
     c->cuPartitionBuilt = 0;
     if (c->cuPartition > 0) {
         const int words = (c->numCUs + 31) / 32;
@@ -1567,8 +1588,8 @@ int ensurePartition(pt_ctx* c) {
             const bool ext = ((k / 8) + (k % 8)) % 8 < c->cuPartition;
             (ext ? mE : mS)[(size_t)k / 32] |= 1u << (k % 32);
         }
-        HIP_TRY(hipExtStreamCreateWithCUMask(&c->sExt, (uint32_t)words, mE.data()));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&c->sShade, (uint32_t)words, mS.data()));
+        if (!pooledStream((c->device + 1) * 100 + c->cuPartition, &c->sExt)) HIP_TRY(hipExtStreamCreateWithCUMask(&c->sExt, (uint32_t)words, mE.data()));
+        if (!pooledStream((c->device + 1) * 100 + 50 + c->cuPartition, &c->sShade)) HIP_TRY(hipExtStreamCreateWithCUMask(&c->sShade, (uint32_t)words, mS.data()));
         if (!c->evExt) { HIP_TRY(hipEventCreateWithFlags(&c->evExt, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evShade, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&c->evHost, hipEventDisableTiming)); }
         c->cuPartitionBuilt = c->cuPartition;
     }
@@ -1580,16 +1601,8 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
 // rows are still owned by unretired batches.
 // The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
-// A stream that is never synchronised must still be LOOKED AT through the runtime: with launches queued for seconds and no hipStreamSynchronize / hipStreamQuery on the
-// stream, the HIP runtime (7.0.2 as bundled with torch) wrote into a freed 920-byte object of its own — a reference count released twice — about once in a thousand
-// sequences of one-frame submissions, and the host heap went with it (glibc aborts, std::bad_variant_access out of libamdhip64).  hipStreamQuery makes the runtime
-// retire the commands that have completed; with one per look and per call the same 4000 sequences are clean under a checking allocator
-// (tools/canary_malloc.cpp, profiles/r06_f_runtime_write_after_free.txt).  The round-5 scheduler synchronised the stream at every look and never met this.
-inline void reapStream(pt_ctx* c) { static const bool off = std::getenv("PT_NO_REAP") != nullptr; if (!off) (void)hipStreamQuery(c->stream); }
-
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
-    reapStream(c);
     // has the group's stamp arrived?  (k_snapshot writes it behind a system-scope fence after the snapshot; pinned coherent memory needs no synchronisation to be read)
     auto landed = [&]() { return *g.stamp == g.seq; };
     if (!landed()) {
@@ -1736,7 +1749,6 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
         return 0;
     };
     int rc;
-    reapStream(c);
     bool kick = until == PUMP_ISSUED;                             // a submission always gets the GPU going: about as many iterations as consume what it added
     while (c->grpCount > 0 && (rc = processOldestGroup(c, false, false)) != 0) if (rc < 0) return rc;      // whatever has finished since the last call
     for (;;) {
@@ -1920,21 +1932,6 @@ extern "C" {
 const char* pt_last_error(void) { return g_err.c_str(); }
 
 namespace {
-// The streams of destroyed contexts are kept for later contexts of the process instead of being destroyed: hipStreamDestroy right behind a long asynchronous run
-// (hundreds of commands retired moments ago) is where the HIP runtime wrote into a freed object of its own (see reapStream).  Streams are few and small.
-std::mutex g_streamPoolLock;
-std::vector<std::pair<int, hipStream_t>> g_streamPool;
-int takeStream(int device, hipStream_t* out) {
-    {
-        std::lock_guard<std::mutex> lk(g_streamPoolLock);
-        for (size_t k = 0; k < g_streamPool.size(); k++)
-            if (g_streamPool[k].first == device) { *out = g_streamPool[k].second; g_streamPool.erase(g_streamPool.begin() + (long)k); return 0; }
-    }
-    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-    return 0;
-}
-void giveStream(int device, hipStream_t s) { std::lock_guard<std::mutex> lk(g_streamPoolLock); g_streamPool.emplace_back(device, s); }
-
 int initContext(pt_ctx* c, int width, int height, int shard_rank, int shard_count) {
     { const int rc = takeStream(c->device, &c->ownStream); if (rc) return rc; }
     c->stream = c->ownStream;
@@ -2066,8 +2063,8 @@ int pt_destroy(pt_ctx* c) {
     if (c->hFrameIn) hipHostFree(c->hFrameIn);
     if (c->hSeeds) hipHostFree(c->hSeeds);
     for (auto& k : c->kt) for (auto& e : k.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    if (c->sExt) hipStreamDestroy(c->sExt);
-    if (c->sShade) hipStreamDestroy(c->sShade);
+    if (c->sExt) { hipStreamSynchronize(c->sExt); giveStream((c->device + 1) * 100 + c->cuPartitionBuilt, c->sExt); }
+    if (c->sShade) { hipStreamSynchronize(c->sShade); giveStream((c->device + 1) * 100 + 50 + c->cuPartitionBuilt, c->sShade); }
     for (hipEvent_t e : {c->evExt, c->evShade, c->evHost}) if (e) hipEventDestroy(e);
     if (c->ownStream) { hipStreamSynchronize(c->ownStream); giveStream(c->device, c->ownStream); }
     delete c;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # under the checking allocator (tools/canary_malloc.cpp: write past the end / write after free of any heap block, with the allocating library): the api fuzz with its bursts of
-# one-frame submissions, the drop-in frame loop at full size and a short bench.   fuzz_bisect.sh <tag> [api-fuzz count]
+# one-frame submissions, the drop-in frame loop at full size and a short bench.   canary_check.sh <tag> [api-fuzz count]
 R=${GRAFT_REPO_ROOT:-$(pwd)}; T=${1:-canary}; O=$R/gpurun_out/$T; mkdir -p $O; cd $R
 g++ -O1 -fPIC -shared -o build/canary_malloc.so tools/canary_malloc.cpp -ldl -lpthread || exit 1
 export LD_PRELOAD=$R/build/canary_malloc.so GPU_MAX_HW_QUEUES=8
