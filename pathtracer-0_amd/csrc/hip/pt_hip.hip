@@ -800,8 +800,9 @@ __global__ void __launch_bounds__(64) k_debug_heatmap(DevScene sc, Batch b, cons
 // them (ascending): a live slot on frame f keeps the first batch with f < ends.f[k] busy.  One pass over the flags per host poll.
 struct ScanEnds { unsigned f[8]; int n; };
 // The host's look at the scheduler words: ONE wave copies Control into the group's snapshot in pinned, coherent host memory and, behind a system-scope fence, writes
-// the group's number into the group's stamp.  A kernel, not hipMemcpyAsync: the runtime's device-to-host copy into pinned memory, left without a hipStreamSynchronize
-// behind it, released one of its own objects twice (a write into freed memory inside libamdhip64, found by tools/canary_malloc.cpp: profiles/r06_f_looks_without_the_copy_engine.txt).
+// the group's number into the group's stamp.  The host reads both without a runtime call (no event, no copy engine, no synchronisation of the stream): this is the form
+// that was verified under the checking allocator while a host heap corruption was being traced (profiles/r06_f_runtime_write_after_free.txt; its cause turned out to be
+// hipStreamDestroy, see takeStream).
 __global__ void __launch_bounds__(64) k_snapshot(const Control* ctl, Control* snap, volatile unsigned* stamp, unsigned seq) {
     const unsigned* s = reinterpret_cast<const unsigned*>(ctl);
     unsigned* d = reinterpret_cast<unsigned*>(snap);
@@ -933,11 +934,10 @@ struct pt_ctx {
     unsigned streamFrames = 0, streamJobs = 0, lastNextJob = 0, lastDelta = 0, launched = 0; int lastCheck = 24, iter = 0; bool draining = false;
     uint64_t lastSubmitJobs = 0, jobsThisImage = 0, jobsPerImage = 0;      // what the last submission added; jobs submitted for the current / the previous FRAME image
     FrameIn* dFrameIn = nullptr; FrameConst* dFc = nullptr; Control* dCtl = nullptr;
-    // The host polls the device's scheduler words once per GROUP of iterations: a group = its launches + (a scan of the oldest batches) + a copy of Control into
-    // the group's pinned snapshot + a copy of the group's number into the group's pinned STAMP behind it.  Up to two groups are in flight: the host looks at a snapshot when
+    // The host looks at the device's scheduler words once per GROUP of iterations: a group = its launches + (a scan of the oldest batches) + k_snapshot, which writes
+    // Control into the group's pinned snapshot and then the group's number into the group's pinned STAMP.  Up to two groups are in flight: the host looks at a snapshot when
     // its stamp has arrived, so the stream always holds the next group's launches while one runs, and an asynchronous submission never waits for the iterations it started
-    // (pump).  Snapshot and stamp are written by a KERNEL (k_snapshot) into coherent pinned memory and read by the host without any runtime call: the runtime's own
-    // device-to-host copy, with events or stamps behind it instead of a hipStreamSynchronize, corrupted the host heap (profiles/r06_f_looks_without_the_copy_engine.txt).
+    // (pump).
     struct Group { Control* h = nullptr; volatile unsigned* stamp = nullptr; unsigned seq = 0; int check = 0, iterEnd = 0, nScan = 0; unsigned scanF0 = 0, epoch = 0; int64_t predicted = 0; };
     Group grp[2]; int grpHead = 0, grpCount = 0; bool scanInFlight = false; unsigned submitEpoch = 0, groupSeq = 0;
     int64_t inflightPredicted = 0;  // jobs the groups in flight are expected to hand out (iterations x the rate of the last look): lastNextJob is as old as the oldest of them
@@ -1600,7 +1600,7 @@ enum PumpUntil { PUMP_IDLE, PUMP_ISSUED, PUMP_IMAGE, PUMP_RING };
 // PUMP_IDLE: every batch retired.  PUMP_ISSUED: the jobs not yet handed out fit into roughly one more group of iterations
 // (never waits for the pool to run dry).  PUMP_IMAGE: no unretired batch targets image `arg`.  PUMP_RING: at most `arg` ring
 // rows are still owned by unretired batches.
-// The oldest group in flight: its snapshot of Control, once its event has fired (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
+// The oldest group in flight: its snapshot of Control, once its stamp has arrived (wait = false: only if it already has).  1 = looked at, 0 = not ready yet, < 0 = PT_ERR_*.
 int processOldestGroup(pt_ctx* c, bool wait, bool discard) {
     pt_ctx::Group& g = c->grp[(c->grpHead + 2 - c->grpCount) % 2];
     // has the group's stamp arrived?  (k_snapshot writes it behind a system-scope fence after the snapshot; pinned coherent memory needs no synchronisation to be read)
@@ -1679,7 +1679,7 @@ int pump(pt_ctx* c, PumpUntil until, int arg) {
     const uint64_t outstanding = (uint64_t)c->streamJobs - std::min<uint64_t>(c->lastNextJob, c->streamJobs) + (uint64_t)N;
     const uint64_t maxIters = 2 * ((outstanding + N - 1) / N + 1) * (uint64_t)(std::ceil(P[4]) * std::ceil(P[5]) + 1) + 64 + 48;
     uint64_t iters = 0;
-    // One group: its iterations, a scan of the oldest batches once they have been handed out completely, the snapshot of Control, the event.
+    // One group: its iterations, a scan of the oldest batches once they have been handed out completely, the snapshot of Control with its stamp.
     // The device runs the schedule by itself: slots pull jobs while there are any; from the iteration after the first empty
     // pull on, every shading launch packs the surviving slots into a dense queue for the next iteration (Control::exhausted).
     // The host only looks: while jobs remain the end is at least one whole job (>= SAMPLE_RES iterations) away, so a group is
