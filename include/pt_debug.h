@@ -37,7 +37,8 @@ extern "C" {
  * 20 = per-ray cull of the object loop in the hand-written intersect kernel for scenes with more than 8 BVHs (one pass over at most 64 group boxes when a ray
  *      starts; the objects of a group whose box the ray misses are never tested): 1 (default) on, 0 off (every group box infinite: each root box is tested in turn).
  * Queries (tests): 12 = PT_OK iff the current scene runs on the hand-written intersect kernel (else PT_ERR_UNSUPPORTED and the reason in pt_last_error),
- * 13 = PT_OK iff that kernel has been launched more than `value` times by this context.  * 21 = spatial partition, an experiment that is NOT the default (profiles/r06_c_cu_partition.txt: every split 25-68 % slower): e = 1..7 puts the intersect launches on a
+ * 13 = PT_OK iff that kernel has been launched more than `value` times by this context.
+ * 21 = spatial partition, an experiment that is NOT the default (profiles/r06_c_cu_partition.txt: every split 25-68 % slower): e = 1..7 puts the intersect launches on a
  *      stream whose CU mask holds e eighths of every XCD's CUs and the shading launches on the complement (hipExtStreamCreateWithCUMask); 0 = off.
  */
 int pt_set_option(pt_ctx* ctx, int option, int64_t value);
